@@ -1,0 +1,109 @@
+"""BioViL image encoder restated with F.conv2d / F.batch_norm / F.max_pool2d (CPU fp32).
+TEST INFRASTRUCTURE ONLY.
+
+Follows `health_multimodal/image/model/resnet.py:25-47` (stem -> maxpool -> layer1..4, returns the
+layer-4 map), `model.py:141-154` (`ImageModel.forward`: trunk -> projector -> spatial mean),
+`model.py:197-205` (`ImageEncoder.forward`) and `modules.py:29-47` (projector: 1x1 conv without bias,
+BatchNorm2d, ReLU, 1x1 conv with bias).  The trunk is torchvision 0.10 `ResNet(Bottleneck,[3,4,6,3])`
+("v1.5": stride on the 3x3, expansion 4, BN eps 1e-5, downsample = 1x1 stride-s conv + BN on the first
+block of every stage).  torchvision is not installed in the build image, so this restatement is
+"parity unpinned" for the trunk; the projector is pinned against the reference's own
+`modules.MLP` in `oracle/gen_golden.py`.
+
+BatchNorm runs in eval mode (running statistics) by default: the only mode the reference ever uses
+the encoder in (`chexpert-get-embedding.py:41-42`).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn.functional as F
+
+P = Dict[str, torch.Tensor]
+LAYERS = (3, 4, 6, 3)
+PLANES = (64, 128, 256, 512)
+BN_EPS = 1e-5
+
+
+def _bn(p: P, name: str, x: torch.Tensor, training: bool = False) -> torch.Tensor:
+    return F.batch_norm(x, p[name + ".running_mean"], p[name + ".running_var"], p[name + ".weight"],
+                        p[name + ".bias"], training=training, eps=BN_EPS)
+
+
+def bottleneck(p: P, pre: str, x: torch.Tensor, stride: int, has_down: bool) -> torch.Tensor:
+    idt = x
+    o = F.relu(_bn(p, pre + "bn1", F.conv2d(x, p[pre + "conv1.weight"])))
+    o = F.relu(_bn(p, pre + "bn2", F.conv2d(o, p[pre + "conv2.weight"], stride=stride, padding=1)))
+    o = _bn(p, pre + "bn3", F.conv2d(o, p[pre + "conv3.weight"]))
+    if has_down:
+        idt = _bn(p, pre + "downsample.1", F.conv2d(x, p[pre + "downsample.0.weight"], stride=stride))
+    return F.relu(o + idt)
+
+
+def resnet50_trunk(p: P, x: torch.Tensor, prefix: str = "encoder.encoder.", collect: List = None) -> torch.Tensor:
+    x = F.conv2d(x, p[prefix + "conv1.weight"], stride=2, padding=3)
+    x = F.relu(_bn(p, prefix + "bn1", x))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    if collect is not None:
+        collect.append(x)
+    for li, (nblk, planes) in enumerate(zip(LAYERS, PLANES), start=1):
+        for b in range(nblk):
+            stride = 2 if (b == 0 and li > 1) else 1
+            x = bottleneck(p, f"{prefix}layer{li}.{b}.", x, stride, has_down=(b == 0))
+        if collect is not None:
+            collect.append(x)
+    return x
+
+
+def projector(p: P, patch: torch.Tensor, prefix: str = "projector.model.") -> torch.Tensor:
+    h = F.conv2d(patch, p[prefix + "0.weight"])
+    h = F.relu(_bn(p, prefix + "1", h))
+    return F.conv2d(h, p[prefix + "3.weight"], p[prefix + "3.bias"])
+
+
+def image_model_forward(p: P, x: torch.Tensor, collect: List = None) -> torch.Tensor:
+    """`ImageModel.forward` (model.py:141-154): returns the projected global embedding [B,128]."""
+    patch = resnet50_trunk(p, x, collect=collect)
+    proj = projector(p, patch)
+    return proj.mean(dim=(2, 3))
+
+
+def image_param_shapes(joint: int = 128) -> Tuple[Dict[str, tuple], Dict[str, tuple]]:
+    """(parameters, buffers) name -> shape, in torchvision/BioViL state-dict naming."""
+    prm: Dict[str, tuple] = {}
+    buf: Dict[str, tuple] = {}
+
+    def bn(name, c):
+        prm[name + ".weight"] = (c,)
+        prm[name + ".bias"] = (c,)
+        buf[name + ".running_mean"] = (c,)
+        buf[name + ".running_var"] = (c,)
+        buf[name + ".num_batches_tracked"] = ()
+
+    e = "encoder.encoder."
+    prm[e + "conv1.weight"] = (64, 3, 7, 7)
+    bn(e + "bn1", 64)
+    inpl = 64
+    for li, (nblk, planes) in enumerate(zip(LAYERS, PLANES), start=1):
+        for b in range(nblk):
+            pre = f"{e}layer{li}.{b}."
+            prm[pre + "conv1.weight"] = (planes, inpl, 1, 1)
+            bn(pre + "bn1", planes)
+            prm[pre + "conv2.weight"] = (planes, planes, 3, 3)
+            bn(pre + "bn2", planes)
+            prm[pre + "conv3.weight"] = (planes * 4, planes, 1, 1)
+            bn(pre + "bn3", planes * 4)
+            if b == 0:
+                prm[pre + "downsample.0.weight"] = (planes * 4, inpl, 1, 1)
+                bn(pre + "downsample.1", planes * 4)
+            inpl = planes * 4
+    # torchvision's ResNet also owns an (unused here) fc layer; BioViL checkpoints carry it
+    prm[e + "fc.weight"] = (1000, 2048)
+    prm[e + "fc.bias"] = (1000,)
+    pj = "projector.model."
+    prm[pj + "0.weight"] = (joint, 2048, 1, 1)
+    bn(pj + "1", joint)
+    prm[pj + "3.weight"] = (joint, joint, 1, 1)
+    prm[pj + "3.bias"] = (joint,)
+    return prm, buf
