@@ -1,0 +1,164 @@
+/* cxrk — C-ABI of the MI355X (gfx950) kernels behind the joint image+text contrastive training step.
+ *
+ * The reference (marcomistretta/incremental_multimodal_medical_learning_II) is pure Python on PyTorch: it has no
+ * FFI layer of its own, so each entry point cites the Python function whose arithmetic it replaces
+ * (paths relative to the reference root).  The host side (incremental_multimodal_medical_learning_ii_amd/) binds this
+ * library with ctypes and keeps the reference's class / method surface; INTEGRATION.md shows the binding stub.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes; fp32 data; int64 ids/masks; no hidden allocation, no hidden synchronisation;
+ *   - work is enqueued on `stream` (the caller's current HIP stream) and the call returns immediately;
+ *   - scratch memory is passed in (`ws`, `ws_bytes`); the matching `*_ws_bytes` function sizes it;
+ *   - return 0 on success, <0 on error: -1 bad argument/alignment, -2 workspace too small, -3 launch failure,
+ *     -4 unsupported shape.  The Python wrappers raise RuntimeError/ValueError for these, mirroring the
+ *     reference's exception behaviour;
+ *   - row-major tensors; activations of the image encoder are NHWC, filters are [Ko][R][S][C] (= a torch OIHW
+ *     tensor in channels_last memory format).
+ */
+#ifndef CXRK_H
+#define CXRK_H
+
+#include <stddef.h>
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------------------
+ * gemm_bias_act — every nn.Linear of the path: BERT query/key/value/dense/intermediate/output
+ * (HF BertLayer under health_multimodal/text/model/modelling_cxrbert.py:87-95), BertProjectionHead
+ * (modelling_cxrbert.py:43-49), models.myMLP / myLinearModel (models.py:7-26), the projector's 1x1 conv with bias
+ * (health_multimodal/image/model/modules.py:32-33) and the logits block I_hat @ T_hat^T.
+ *   C[M,N] = act( alpha * op(A)[M,K] @ op(B)[K,N] + bias[N] + R ) (* gelu'(aux) | * (aux>0))
+ *   transA=0: A[m*lda+k]   transA=1: A[k*lda+m]      transB=0: B[k*ldb+n]   transB=1: B[n*ldb+k]
+ *   act: 0 none, 1 relu, 2 gelu(erf).  auxmode: 0 none, 1 multiply by (aux>0), 2 multiply by gelu'(aux).
+ *   C2 (optional) receives the pre-activation value.  accumulate: C += result (R must be NULL).
+ *   splitk>1: deterministic split-K through `ws` (plain epilogue only) — used for weight gradients.
+ * fwd:  Y = X W^T + b           -> transA=0, transB=1
+ * bwd:  dX = dY W               -> transA=0, transB=0 ;  dW = dY^T X -> transA=1, transB=0 (split-K)
+ */
+size_t cxrk_gemm_splitk_ws_bytes(int M, int N, int splitk);
+int cxrk_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                  float* C, long ldc, const float* bias, const float* R, long ldr, const float* aux, long ldaux,
+                  int auxmode, float* C2, long ldc2, int act, float alpha, int accumulate, int splitk, float* ws,
+                  size_t ws_bytes, hipStream_t stream);
+
+/* out[cols] (+)= alpha * sum_rows X[rows, cols] — bias gradients, BN beta gradients, position/type embedding grads. */
+size_t cxrk_colsum_ws_bytes(long rows, int cols);
+int cxrk_colsum(const float* X, long ldx, long rows, int cols, float* out, float alpha, int accumulate, float* ws,
+                size_t ws_bytes, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * conv_bn_act — torchvision Bottleneck conv + eval-mode BatchNorm + ReLU (+ residual) as used by
+ * health_multimodal/image/model/resnet.py:34-47 and the projector's conv+BN+ReLU (modules.py:43-46).
+ * cxrk_bn_fold: w_scaled = w * gamma*rsqrt(var+eps) (per output channel, channel-padded to Cpad),
+ *               scale = gamma*rstd, shift = beta - mean*scale, rstd = rsqrt(var+eps).
+ * fwd:        y = relu?( conv(x, w_scaled) + shift + residual? )
+ * bwd_data:   dx = (relu_src>0)? * ( conv^T(dy, w_scaled) + residual? )        (dy already masked by its own ReLU)
+ * bwd_params: dW = scale * wgrad(x, dy);  dgamma = rstd*(<w,wgrad> - mean*sumdy);  dbeta = sumdy
+ */
+int cxrk_bn_fold(const float* w, const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                 float eps, int Ko, int taps, int C, int Cpad, float* w_scaled, float* scale, float* shift,
+                 float* rstd, hipStream_t stream);
+int cxrk_conv_bn_act_fwd(const float* x, const float* w_scaled, const float* shift, const float* residual, float* y,
+                         int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad, int relu,
+                         hipStream_t stream);
+int cxrk_conv_bn_act_bwd_data(const float* dy, const float* w_scaled, const float* residual, const float* relu_src,
+                              float* dx, int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad,
+                              hipStream_t stream);
+size_t cxrk_conv_wgrad_ws_bytes(int N, int H, int W, int Cpad, int Ko, int R, int S, int stride, int pad);
+int cxrk_conv_bn_act_bwd_params(const float* x, const float* dy, const float* w, const float* scale, const float* rstd,
+                                const float* rmean, const float* sumdy, float* dw, float* dgamma, float* dbeta,
+                                int accumulate, int N, int H, int W, int C, int Cpad, int Ko, int R, int S, int stride,
+                                int pad, float* ws, size_t ws_bytes, hipStream_t stream);
+
+/* Boundary layout transforms: torch NCHW input (model.py:141) <-> NHWC working layout. */
+int cxrk_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, hipStream_t stream);
+int cxrk_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, hipStream_t stream);
+
+/* maxpool — nn.MaxPool2d(3, stride 2, pad 1) of the ResNet stem (resnet.py:37). idx = winning tap per output. */
+int cxrk_maxpool_fwd(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, hipStream_t stream);
+int cxrk_maxpool_bwd(const float* dy, const unsigned char* idx, const float* x, float* dx, int N, int H, int W, int C,
+                     int relu_mask, hipStream_t stream);
+
+/* spatial_mean — torch.mean(projected_patch_embeddings, dim=(2,3)) (model.py:145). x[N][P][C] -> y[N][C]. */
+int cxrk_spatial_mean_fwd(const float* x, float* y, int N, int P, int C, hipStream_t stream);
+int cxrk_spatial_mean_bwd(const float* dy, float* dx, int N, int P, int C, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * CXR-BERT pieces (HF BertForMaskedLM under modelling_cxrbert.py:87-99; config configuration_cxrbert.py:11-22).
+ * embed_ln:    y = LayerNorm(word[ids] + pos[t % L] + type[0])                    (BertEmbeddings)
+ * residual_ln: y = LayerNorm(x + res)                                             (BertSelfOutput / BertOutput)
+ *              xhat, rstd saved for bwd; bwd: dx = LN'(dy) + dx_add, dgamma/dbeta reduced deterministically.
+ * attn:        ctx = softmax(Q K^T / sqrt(d) + keymask) V per (sequence, head); qkv is the fused [T][3*nH*d]
+ *              projection output; probs [B][nH][L][L] saved for bwd.  L <= 64, d == 64.
+ * embed_bwd:   dword[ids[t]] += dx[t]   (fp32 atomics)
+ */
+int cxrk_embed_ln_fwd(const long* ids, const float* word, const float* pos, const float* type, const float* gamma,
+                      const float* beta, float eps, long T, int L, int H, float* y, float* xhat, float* rstd,
+                      hipStream_t stream);
+int cxrk_residual_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps, long rows,
+                         int H, float* y, float* xhat, float* rstd, hipStream_t stream);
+size_t cxrk_residual_ln_bwd_ws_bytes(long rows, int H);
+int cxrk_residual_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, long rows, int H,
+                         const float* dx_add, float* dx, float* dgamma, float* dbeta, int accumulate, float* ws,
+                         size_t ws_bytes, hipStream_t stream);
+int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, int nH, int dH, float* ctx, float* probs,
+                  hipStream_t stream);
+int cxrk_attn_bwd(const float* qkv, const float* probs, const float* dctx, int B, int L, int nH, int dH, float* dqkv,
+                  hipStream_t stream);
+int cxrk_embed_bwd(const long* ids, const float* dx, long T, int H, float* dword, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Similarity / loss heads.
+ * l2norm:      F.normalize(x, dim=1) (modelling_cxrbert.py:138-139; vlp/inference_engine.py:51): xhat = x / max(|x|, eps).
+ * infonce:     north-star head (not in the reference): on a logits block S[rows][cols] = X_hat_local @ Y_hat_all^T / tau,
+ *              row_lse gives lse + diagonal (+ accumulates sum(lse-diag)*scale into loss_out);
+ *              grad_inplace turns S into exp(S-lse_row[i]) + exp(S-lse_col[j]) - 2*[j==diag_off+i].
+ * pairwise_cosine: torchmetrics pairwise_cosine_similarity as called by Trainer.myCosineSimilarity (Trainer.py:1682-1704).
+ * bce_posneg:  logits = cos_pos - cos_neg (Trainer.py:575) + nn.BCEWithLogitsLoss() mean (ZERO_JOINT_BOUNDS.py:36);
+ *              cos is [B][2C] with column 2c = positive prompt of class c, 2c+1 = negative; writes dloss/dcos.
+ * eval_score:  Trainer.val/test scoring (Trainer.py:825-836).
+ * group_mean:  prompt-embedding mean over the prompts of a class (Trainer.py:1665-1666).
+ */
+int cxrk_l2norm_fwd(const float* x, long rows, int D, float eps, float* xhat, float* norm, hipStream_t stream);
+int cxrk_l2norm_bwd(const float* dxhat, const float* xhat, const float* norm, long rows, int D, float* dx,
+                    hipStream_t stream);
+int cxrk_infonce_row_lse(const float* S, long ld, int rows, int cols, int diag_off, float* lse, float* diag,
+                         float* loss_out, float loss_scale, int loss_accumulate, hipStream_t stream);
+int cxrk_infonce_grad_inplace(float* S, long ld, int rows, int cols, int diag_off, const float* lse_row,
+                              const float* lse_col, hipStream_t stream);
+int cxrk_pairwise_cosine_fwd(const float* x, const float* y, long B, int P, int D, float* cosv, float* xnorm,
+                             float* ynorm, hipStream_t stream);
+size_t cxrk_pairwise_cosine_bwd_ws_bytes(long B, int P, int D);
+int cxrk_pairwise_cosine_bwd(const float* x, const float* y, const float* cosv, const float* dcos, const float* xnorm,
+                             const float* ynorm, long B, int P, int D, float* dx, float* dy, int accumulate_dy,
+                             float* ws, size_t ws_bytes, hipStream_t stream);
+size_t cxrk_bce_posneg_ws_bytes(void);
+int cxrk_bce_posneg_fwd_bwd(const float* cosv, const float* labels, long B, int C, int ldlab, int diff, float* logits,
+                            float* dcos, float* loss, float* ws, size_t ws_bytes, hipStream_t stream);
+int cxrk_eval_score(const float* cosv, long B, int C, int pred_diff, float* score, float* pred, hipStream_t stream);
+int cxrk_group_mean_fwd(const float* in, int G, int n, int D, float* out, hipStream_t stream);
+int cxrk_group_mean_bwd(const float* dout, int G, int n, int D, float* din, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimiser / continual learning.
+ * adam_fused:   torch.optim.Adam defaults (Trainer.py:172-175), one launch over a flat parameter buffer.
+ * sgd:          optim.SGD (Trainer.py:176-178).
+ * weight_reset: Trainer.myIncremental per tensor (Trainer.py:1562-1572); counters[0] += #restored.
+ */
+int cxrk_adam_fused(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, float grad_scale, hipStream_t stream);
+int cxrk_sgd(float* p, const float* g, long n, float lr, float weight_decay, float grad_scale, hipStream_t stream);
+size_t cxrk_weight_reset_ws_bytes(void);
+int cxrk_weight_reset(float* pnew, const float* pold, long n, float threshold, unsigned long long* counters, float* ws,
+                      size_t ws_bytes, hipStream_t stream);
+
+/* Library identification: returns a static string "cxrk <version> gfx950". */
+const char* cxrk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CXRK_H */

@@ -1,0 +1,324 @@
+// ResNet-50 image-encoder kernels: NHWC implicit-GEMM convolution (fprop / dgrad / wgrad) on the shared fp32 MFMA
+// mainloop, eval-mode BatchNorm folding, the wgrad slab reduction that also produces the BN parameter gradients,
+// max-pool, spatial mean and the NCHW<->NHWC boundary transforms.
+//
+// Reference semantics: health_multimodal/image/model/resnet.py:25-47 (stem, maxpool, layer1..4),
+// torchvision ResNet-50 v1.5 Bottleneck (stride on the 3x3), model.py:141-154 and modules.py:29-47 (projector).
+#include "cxrk.h"
+#include "gemm_core.h"
+
+using namespace cxrk;
+
+namespace {
+
+ConvGeom make_geom(int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad) {
+  ConvGeom g;
+  g.N = N; g.H = H; g.W = W; g.C = C; g.Ko = Ko; g.R = R; g.S = S; g.stride = stride; g.pad = pad;
+  g.Ho = (H + 2 * pad - R) / stride + 1;
+  g.Wo = (W + 2 * pad - S) / stride + 1;
+  return g;
+}
+
+// w_scaled[ko][tap][c<Cpad] = w[ko][tap][c] * gamma[ko]*rsqrt(var[ko]+eps)  (0 for c >= C)
+__global__ void bn_fold_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, int Ko, int taps,
+                               int C, int Cpad, float* __restrict__ ws, float* __restrict__ scale, float* __restrict__ shift,
+                               float* __restrict__ rstd) {
+  const int ko = blockIdx.x;
+  const float rs = 1.0f / sqrtf(rvar[ko] + eps);
+  const float sc = gamma[ko] * rs;
+  if (threadIdx.x == 0) { scale[ko] = sc; shift[ko] = beta[ko] - rmean[ko] * sc; rstd[ko] = rs; }
+  const int n = taps * Cpad;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int tap = i / Cpad, c = i - tap * Cpad;
+    ws[(long)ko * n + i] = c < C ? w[((long)ko * taps + tap) * C + c] * sc : 0.f;
+  }
+}
+
+// One block per output channel: dW[ko] = scale[ko] * sum_z slab_z[ko], dgamma, dbeta.
+//   dgamma[ko] = rstd[ko] * ( <w[ko], dWraw[ko]> - rmean[ko] * sumdy[ko] ),  dbeta[ko] = sumdy[ko]
+// (sum_{n,h,w} dy*z = <w, dWraw> because z is linear in w; see DESIGN.md "BatchNorm in eval mode").
+__global__ void wgrad_reduce_bn_kernel(const float* __restrict__ slabs, int nslab, long slab_stride, int taps, int C, int Cpad,
+                                       const float* __restrict__ w, const float* __restrict__ scale,
+                                       const float* __restrict__ rstd, const float* __restrict__ rmean,
+                                       const float* __restrict__ sumdy, float* __restrict__ dw, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int accumulate) {
+  __shared__ float sh[16];
+  const int ko = blockIdx.x;
+  const int n = taps * Cpad;
+  const float sc = scale ? scale[ko] : 1.f;
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float s = 0.f;
+    for (int z = 0; z < nslab; ++z) s += slabs[(long)z * slab_stride + (long)ko * n + i];
+    const int tap = i / Cpad, c = i - tap * Cpad;
+    if (c < C) {
+      const long o = ((long)ko * taps + tap) * C + c;
+      dot += w[o] * s;
+      dw[o] = accumulate ? dw[o] + sc * s : sc * s;
+    }
+  }
+  if (dgamma) {
+    dot = block_sum(dot, sh);
+    if (threadIdx.x == 0) {
+      const float g = rstd[ko] * (dot - rmean[ko] * sumdy[ko]);
+      dgamma[ko] = accumulate ? dgamma[ko] + g : g;
+      dbeta[ko] = accumulate ? dbeta[ko] + sumdy[ko] : sumdy[ko];
+    }
+  }
+}
+
+// x[N][C][H][W] -> y[N][H][W][Cpad] (zero channel padding).  One block per (n, h): a W x C tile through LDS.
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int H, int W, int Cpad) {
+  const long nh = blockIdx.x;  // n*H + h
+  const long n = nh / H; const int hh = (int)(nh - n * H);
+  for (int i = threadIdx.x; i < W * Cpad; i += blockDim.x) {
+    const int wv = i / Cpad, c = i - wv * Cpad;
+    y[(nh * W + wv) * Cpad + c] = c < C ? x[((n * C + c) * H + hh) * W + wv] : 0.f;
+  }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int H, int W) {
+  const long nh = blockIdx.x;
+  const long n = nh / H; const int hh = (int)(nh - n * H);
+  for (int i = threadIdx.x; i < W * C; i += blockDim.x) {
+    const int c = i / W, wv = i - c * W;
+    y[((n * C + c) * H + hh) * W + wv] = x[(nh * W + wv) * C + c];
+  }
+}
+
+// 3x3 / stride 2 / pad 1 max-pool, NHWC, 4 channels per thread.  idx = winning tap (first maximum in scan order,
+// as torch's max_pool2d backward routes the gradient).
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx,
+                                   int N, int H, int W, int C, int Ho, int Wo) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int C4 = C / 4;
+  const long total = (long)N * Ho * Wo * C4;
+  if (t >= total) return;
+  const int c4 = (int)(t % C4); long p = t / C4;
+  const int wo = (int)(p % Wo); p /= Wo; const int ho = (int)(p % Ho); const long n = p / Ho;
+  float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  uchar4 bi = make_uchar4(0, 0, 0, 0);
+  bool first = true;
+  for (int r = 0; r < 3; ++r) {
+    const int hi = ho * 2 - 1 + r;
+    if ((unsigned)hi >= (unsigned)H) continue;
+    for (int s = 0; s < 3; ++s) {
+      const int wi = wo * 2 - 1 + s;
+      if ((unsigned)wi >= (unsigned)W) continue;
+      const float4 v = *reinterpret_cast<const float4*>(x + ((n * H + hi) * W + wi) * C + c4 * 4);
+      const unsigned char tap = (unsigned char)(r * 3 + s);
+      if (first || v.x > best.x) { best.x = v.x; bi.x = tap; }
+      if (first || v.y > best.y) { best.y = v.y; bi.y = tap; }
+      if (first || v.z > best.z) { best.z = v.z; bi.z = tap; }
+      if (first || v.w > best.w) { best.w = v.w; bi.w = tap; }
+      first = false;
+    }
+  }
+  *reinterpret_cast<float4*>(y + t * 4) = best;
+  *reinterpret_cast<uchar4*>(idx + t * 4) = bi;
+}
+
+// dx[n][hi][wi][c] = (x > 0) * sum over the <=4 windows covering (hi,wi) whose winning tap is this pixel.
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                   const float* __restrict__ x, float* __restrict__ dx, int N, int H, int W, int C, int Ho,
+                                   int Wo, int relu_mask) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int C4 = C / 4;
+  const long total = (long)N * H * W * C4;
+  if (t >= total) return;
+  const int c4 = (int)(t % C4); long p = t / C4;
+  const int wi = (int)(p % W); p /= W; const int hi = (int)(p % H); const long n = p / H;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = 0; r < 3; ++r) {
+    const int hn = hi + 1 - r;
+    if (hn < 0 || (hn & 1)) continue;
+    const int ho = hn >> 1;
+    if (ho >= Ho) continue;
+    for (int s = 0; s < 3; ++s) {
+      const int wn = wi + 1 - s;
+      if (wn < 0 || (wn & 1)) continue;
+      const int wo = wn >> 1;
+      if (wo >= Wo) continue;
+      const long o = (((n * Ho + ho) * Wo + wo) * C4 + c4) * 4;
+      const uchar4 bi = *reinterpret_cast<const uchar4*>(idx + o);
+      const float4 d = *reinterpret_cast<const float4*>(dy + o);
+      const unsigned char tap = (unsigned char)(r * 3 + s);
+      if (bi.x == tap) g.x += d.x;
+      if (bi.y == tap) g.y += d.y;
+      if (bi.z == tap) g.z += d.z;
+      if (bi.w == tap) g.w += d.w;
+    }
+  }
+  if (relu_mask) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + t * 4);
+    g.x = xv.x > 0.f ? g.x : 0.f; g.y = xv.y > 0.f ? g.y : 0.f; g.z = xv.z > 0.f ? g.z : 0.f; g.w = xv.w > 0.f ? g.w : 0.f;
+  }
+  *reinterpret_cast<float4*>(dx + t * 4) = g;
+}
+
+// y[n][c] = mean_p x[n][p][c]
+__global__ void spatial_mean_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int P, int C) {
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += x[((long)n * P + p) * C + c];
+    y[(long)n * C + c] = s / (float)P;
+  }
+}
+__global__ void spatial_mean_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int P, int C) {
+  const int n = blockIdx.x;
+  const float inv = 1.0f / (float)P;
+  for (int i = threadIdx.x; i < P * C; i += blockDim.x) dx[(long)n * P * C + i] = dy[(long)n * C + (i % C)] * inv;
+}
+
+}  // namespace
+
+extern "C" int cxrk_bn_fold(const float* w, const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                            float eps, int Ko, int taps, int C, int Cpad, float* w_scaled, float* scale, float* shift,
+                            float* rstd, hipStream_t stream) {
+  CXRK_CHECK_ARG(w && gamma && beta && rmean && rvar && w_scaled && scale && shift && rstd && Ko > 0 && taps > 0 && C > 0 && Cpad >= C);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(Ko), dim3(256), 0, stream, w, gamma, beta, rmean, rvar, eps, Ko, taps, C, Cpad,
+                     w_scaled, scale, shift, rstd);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+
+extern "C" int cxrk_conv_bn_act_fwd(const float* x, const float* w_scaled, const float* shift, const float* residual,
+                                    float* y, int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad,
+                                    int relu, hipStream_t stream) {
+  CXRK_CHECK_ARG(x && w_scaled && y && N > 0 && C % 4 == 0 && aligned16(x) && aligned16(w_scaled));
+  CXRK_CHECK_ARG(stride == 1 || stride == 2);
+  const ConvGeom g = make_geom(N, H, W, C, Ko, R, S, stride, pad);
+  CXRK_CHECK_ARG(g.Ho > 0 && g.Wo > 0);
+  const long Ml = (long)N * g.Ho * g.Wo;
+  CXRK_CHECK_ARG(Ml < (1L << 31));
+  const int M = (int)Ml, K = R * S * C;
+  EpiParams ep{};
+  ep.C = y; ep.ldc = Ko; ep.bias = shift; ep.R = residual; ep.ldr = Ko; ep.act = relu ? 1 : 0; ep.alpha = 1.f;
+  int rc;
+  if (Ko <= 64) {
+    ConvIm2colKC<256>::P pa{x, g, M, K}; DenseKC<64>::P pb{w_scaled, (long)K, Ko, K};
+    rc = launch_gemm<ConvIm2colKC<256>, DenseKC<64>, 4, 1>(pa, pb, ep, M, Ko, K, 1, stream);
+  } else {
+    ConvIm2colKC<128>::P pa{x, g, M, K}; DenseKC<128>::P pb{w_scaled, (long)K, Ko, K};
+    rc = launch_gemm<ConvIm2colKC<128>, DenseKC<128>, 2, 2>(pa, pb, ep, M, Ko, K, 1, stream);
+  }
+  return rc < 0 ? rc : CXRK_OK;
+}
+
+// dx[n][hi][wi][c] = mask( sum_{r,s,ko} dy[n][(hi+pad-r)/st][(wi+pad-s)/st][ko] * w_scaled[ko][r][s][c] + residual )
+extern "C" int cxrk_conv_bn_act_bwd_data(const float* dy, const float* w_scaled, const float* residual,
+                                         const float* relu_src, float* dx, int N, int H, int W, int C, int Ko, int R, int S,
+                                         int stride, int pad, hipStream_t stream) {
+  CXRK_CHECK_ARG(dy && w_scaled && dx && N > 0 && C % 4 == 0 && Ko % 4 == 0 && aligned16(dy) && aligned16(w_scaled));
+  CXRK_CHECK_ARG(stride == 1 || stride == 2);
+  const ConvGeom g = make_geom(N, H, W, C, Ko, R, S, stride, pad);
+  const long Ml = (long)N * H * W;
+  CXRK_CHECK_ARG(Ml < (1L << 31));
+  const int M = (int)Ml, K = R * S * Ko;
+  EpiParams ep{};
+  ep.C = dx; ep.ldc = C; ep.R = residual; ep.ldr = C; ep.alpha = 1.f;
+  if (relu_src) { ep.aux = relu_src; ep.ldaux = C; ep.auxmode = 1; }
+  int rc;
+  if (C <= 64) {
+    ConvDgradKC<256>::P pa{dy, g, M, K}; ConvFilterMC<64>::P pb{w_scaled, g, C, K};
+    rc = launch_gemm<ConvDgradKC<256>, ConvFilterMC<64>, 4, 1>(pa, pb, ep, M, C, K, 1, stream);
+  } else {
+    ConvDgradKC<128>::P pa{dy, g, M, K}; ConvFilterMC<128>::P pb{w_scaled, g, C, K};
+    rc = launch_gemm<ConvDgradKC<128>, ConvFilterMC<128>, 2, 2>(pa, pb, ep, M, C, K, 1, stream);
+  }
+  return rc < 0 ? rc : CXRK_OK;
+}
+
+static int wgrad_splitk(int Ko, int Ncols, long Kred) {
+  const int tiles = ceil_div(Ko, Ko <= 64 ? 64 : 128) * ceil_div(Ncols, Ko <= 64 ? 256 : 128);
+  long want = (1536 + tiles - 1) / tiles;            // ~6 blocks per CU
+  const long maxk = (Kred + 8 * BK - 1) / (8 * BK);  // at least 8 K-tiles per slab
+  if (want > maxk) want = maxk;
+  if (want < 1) want = 1;
+  if (want > 2048) want = 2048;
+  return (int)want;
+}
+
+extern "C" size_t cxrk_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad) {
+  const ConvGeom g = make_geom(N, H, W, C, Ko, R, S, stride, pad);
+  const int sk = wgrad_splitk(Ko, R * S * C, (long)N * g.Ho * g.Wo);
+  return (size_t)sk * (size_t)Ko * (size_t)(R * S * C) * sizeof(float);
+}
+
+// dW (+ BN parameter gradients).  x: conv input [N,H,W,Cpad]; dy: gradient w.r.t. the BN output, already ReLU-masked.
+// w: raw (unscaled) filter [Ko][R][S][C]; sumdy[ko] = sum of dy over (n,ho,wo) (cxrk_colsum).  C may be < Cpad (stem).
+extern "C" int cxrk_conv_bn_act_bwd_params(const float* x, const float* dy, const float* w, const float* scale,
+                                           const float* rstd, const float* rmean, const float* sumdy, float* dw,
+                                           float* dgamma, float* dbeta, int accumulate, int N, int H, int W, int C,
+                                           int Cpad, int Ko, int R, int S, int stride, int pad, float* ws, size_t ws_bytes,
+                                           hipStream_t stream) {
+  CXRK_CHECK_ARG(x && dy && dw && N > 0 && Cpad % 4 == 0 && Ko % 4 == 0 && aligned16(x) && aligned16(dy));
+  CXRK_CHECK_ARG(!(dgamma && !(w && rstd && rmean && sumdy && dbeta)));
+  const ConvGeom g = make_geom(N, H, W, Cpad, Ko, R, S, stride, pad);
+  const long Kl = (long)N * g.Ho * g.Wo;
+  CXRK_CHECK_ARG(Kl < (1L << 31));
+  const int Kred = (int)Kl, Nc = R * S * Cpad;
+  int sk = wgrad_splitk(Ko, Nc, Kl);
+  if (ws == nullptr || ws_bytes < (size_t)sk * Ko * Nc * sizeof(float)) return CXRK_ERR_WS;
+  EpiParams ep{};
+  ep.C = ws; ep.ldc = Nc; ep.alpha = 1.f; ep.slab_stride = (long)Ko * Nc;
+  int rc;
+  if (Ko <= 64) {
+    DenseMC<64>::P pa{dy, (long)Ko, Ko, Kred}; ConvIm2colMC<256>::P pb{x, g, Nc, Kred};
+    rc = launch_gemm<DenseMC<64>, ConvIm2colMC<256>, 1, 4>(pa, pb, ep, Ko, Nc, Kred, sk, stream);
+  } else {
+    DenseMC<128>::P pa{dy, (long)Ko, Ko, Kred}; ConvIm2colMC<128>::P pb{x, g, Nc, Kred};
+    rc = launch_gemm<DenseMC<128>, ConvIm2colMC<128>, 2, 2>(pa, pb, ep, Ko, Nc, Kred, sk, stream);
+  }
+  if (rc < 0) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_bn_kernel, dim3(Ko), dim3(256), 0, stream, ws, rc, (long)Ko * Nc, R * S, C, Cpad, w,
+                     scale, rstd, rmean, sumdy, dw, dgamma, dbeta, accumulate);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+
+extern "C" int cxrk_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, hipStream_t stream) {
+  CXRK_CHECK_ARG(x && y && N > 0 && C > 0 && Cpad >= C);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((long)N * H)), dim3(256), 0, stream, x, y, C, H, W, Cpad);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+extern "C" int cxrk_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, hipStream_t stream) {
+  CXRK_CHECK_ARG(x && y && N > 0 && C > 0);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((long)N * H)), dim3(256), 0, stream, x, y, C, H, W);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+
+extern "C" int cxrk_maxpool_fwd(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, hipStream_t stream) {
+  CXRK_CHECK_ARG(x && y && idx && C % 4 == 0 && aligned16(x) && aligned16(y));
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total = (long)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, y, idx, N, H, W, C, Ho, Wo);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+extern "C" int cxrk_maxpool_bwd(const float* dy, const unsigned char* idx, const float* x, float* dx, int N, int H, int W,
+                                int C, int relu_mask, hipStream_t stream) {
+  CXRK_CHECK_ARG(dy && idx && dx && C % 4 == 0 && (!relu_mask || x));
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total = (long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dy, idx, x, dx, N, H, W, C,
+                     Ho, Wo, relu_mask);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+
+extern "C" int cxrk_spatial_mean_fwd(const float* x, float* y, int N, int P, int C, hipStream_t stream) {
+  CXRK_CHECK_ARG(x && y && N > 0 && P > 0 && C > 0);
+  hipLaunchKernelGGL(spatial_mean_fwd_kernel, dim3(N), dim3(128), 0, stream, x, y, P, C);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+extern "C" int cxrk_spatial_mean_bwd(const float* dy, float* dx, int N, int P, int C, hipStream_t stream) {
+  CXRK_CHECK_ARG(dy && dx && N > 0 && P > 0 && C > 0);
+  hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(N), dim3(256), 0, stream, dy, dx, P, C);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}

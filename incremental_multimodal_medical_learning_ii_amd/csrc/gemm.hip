@@ -1,0 +1,128 @@
+// Dense fp32 GEMM entry points (Linear fprop / dgrad / wgrad of CXR-BERT, the projection heads and the adapters)
+// plus the generic column-sum (bias gradients) and split-K slab reduction.
+#include "cxrk.h"
+#include "gemm_core.h"
+
+using namespace cxrk;
+
+namespace {
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int nslab, long slab, float* __restrict__ C, long ldc,
+                                     int N, float alpha, int accumulate) {
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= slab) return;
+  float4 s = *reinterpret_cast<const float4*>(ws + i4);
+  for (int z = 1; z < nslab; ++z) {
+    const float4 t = *reinterpret_cast<const float4*>(ws + (long)z * slab + i4);
+    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  }
+  const long row = i4 / N; const int col = (int)(i4 - row * N);  // N % 4 == 0 -> the 4 values share a row
+  float* c = C + row * ldc + col;
+  if (accumulate) { c[0] += alpha * s.x; c[1] += alpha * s.y; c[2] += alpha * s.z; c[3] += alpha * s.w; }
+  else { c[0] = alpha * s.x; c[1] = alpha * s.y; c[2] = alpha * s.z; c[3] = alpha * s.w; }
+}
+
+// Stage 1 of a deterministic column sum: block (bx, by) sums rows [by*rows_per, ...) of columns bx*256..+255.
+__global__ void colsum_partial_kernel(const float* __restrict__ X, long ldx, long rows, int cols, int rows_per,
+                                      float* __restrict__ part) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= cols) return;
+  const long r0 = (long)blockIdx.y * rows_per;
+  const long r1 = min(rows, r0 + rows_per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  long r = r0;
+  for (; r + 3 < r1; r += 4) {
+    s0 += X[r * ldx + col]; s1 += X[(r + 1) * ldx + col]; s2 += X[(r + 2) * ldx + col]; s3 += X[(r + 3) * ldx + col];
+  }
+  for (; r < r1; ++r) s0 += X[r * ldx + col];
+  part[(long)blockIdx.y * cols + col] = (s0 + s1) + (s2 + s3);
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int cols, float* __restrict__ out,
+                                    float alpha, int accumulate) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= cols) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(long)p * cols + col];
+  out[col] = accumulate ? out[col] + alpha * s : alpha * s;
+}
+
+}  // namespace
+
+extern "C" size_t cxrk_gemm_splitk_ws_bytes(int M, int N, int splitk) {
+  return splitk > 1 ? (size_t)splitk * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" int cxrk_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B,
+                             long ldb, float* C, long ldc, const float* bias, const float* R, long ldr,
+                             const float* aux, long ldaux, int auxmode, float* C2, long ldc2, int act, float alpha,
+                             int accumulate, int splitk, float* ws, size_t ws_bytes, hipStream_t stream) {
+  CXRK_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0);
+  CXRK_CHECK_ARG(aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0));
+  CXRK_CHECK_ARG(transA ? (M % 4 == 0) : (K % 4 == 0));
+  CXRK_CHECK_ARG(transB ? (K % 4 == 0) : (N % 4 == 0));
+  CXRK_CHECK_ARG(!(auxmode != 0 && aux == nullptr));
+  if (splitk < 1) splitk = 1;
+  EpiParams ep{};
+  ep.alpha = alpha; ep.slab_stride = 0;
+  const bool plain = !bias && !R && !aux && !C2 && act == 0;
+  if (splitk > 1) {
+    CXRK_CHECK_ARG(plain && (N % 4 == 0));
+    if (ws == nullptr || ws_bytes < cxrk_gemm_splitk_ws_bytes(M, N, splitk)) return CXRK_ERR_WS;
+    ep.C = ws; ep.ldc = N; ep.alpha = 1.f; ep.slab_stride = (long)M * N;
+  } else {
+    if (accumulate) { CXRK_CHECK_ARG(R == nullptr); ep.R = C; ep.ldr = ldc; }
+    else { ep.R = R; ep.ldr = ldr; }
+    ep.C = C; ep.ldc = ldc; ep.bias = bias; ep.aux = aux; ep.ldaux = ldaux; ep.auxmode = auxmode;
+    ep.C2 = C2; ep.ldc2 = ldc2; ep.act = act;
+  }
+  int rc;
+#define CXRK_TILES(LAT, LBT, pa_expr, pb_expr)                                                                    \
+  if (N <= 64) { LAT<256>::P pa = pa_expr; LBT<64>::P pb = pb_expr;                                               \
+    rc = launch_gemm<LAT<256>, LBT<64>, 4, 1>(pa, pb, ep, M, N, K, splitk, stream); }                             \
+  else if (M <= 64) { LAT<64>::P pa = pa_expr; LBT<256>::P pb = pb_expr;                                          \
+    rc = launch_gemm<LAT<64>, LBT<256>, 1, 4>(pa, pb, ep, M, N, K, splitk, stream); }                             \
+  else { LAT<128>::P pa = pa_expr; LBT<128>::P pb = pb_expr;                                                      \
+    rc = launch_gemm<LAT<128>, LBT<128>, 2, 2>(pa, pb, ep, M, N, K, splitk, stream); }
+#define PA_KC {A, lda, M, K}
+#define PA_MC {A, lda, M, K}
+#define PB_KC {B, ldb, N, K}
+#define PB_MC {B, ldb, N, K}
+  if (!transA && transB) { CXRK_TILES(DenseKC, DenseKC, PA_KC, PB_KC) }
+  else if (!transA && !transB) { CXRK_TILES(DenseKC, DenseMC, PA_KC, PB_MC) }
+  else if (transA && !transB) { CXRK_TILES(DenseMC, DenseMC, PA_MC, PB_MC) }
+  else { CXRK_TILES(DenseMC, DenseKC, PA_MC, PB_KC) }
+#undef CXRK_TILES
+  if (rc < 0) return rc;
+  if (splitk > 1) {
+    const long slab = (long)M * N;
+    const int nblk = ceil_div(slab / 4, 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nblk), dim3(256), 0, stream, ws, rc, slab, C, ldc, N, alpha, accumulate);
+    CXRK_LAUNCH_CHECK();
+  }
+  return CXRK_OK;
+}
+
+extern "C" size_t cxrk_colsum_ws_bytes(long rows, int cols) {
+  int nparts = (int)((rows + 511) / 512);
+  if (nparts > 512) nparts = 512;
+  if (nparts < 1) nparts = 1;
+  return (size_t)nparts * (size_t)cols * sizeof(float);
+}
+
+extern "C" int cxrk_colsum(const float* X, long ldx, long rows, int cols, float* out, float alpha, int accumulate,
+                           float* ws, size_t ws_bytes, hipStream_t stream) {
+  CXRK_CHECK_ARG(X && out && rows > 0 && cols > 0);
+  int nparts = (int)((rows + 511) / 512);
+  if (nparts > 512) nparts = 512;
+  if (nparts < 1) nparts = 1;
+  if (ws == nullptr || ws_bytes < (size_t)nparts * cols * sizeof(float)) return CXRK_ERR_WS;
+  const int rows_per = (int)((rows + nparts - 1) / nparts);
+  nparts = (int)((rows + rows_per - 1) / rows_per);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(cols, 256), nparts), dim3(256), 0, stream, X, ldx, rows, cols,
+                     rows_per, ws);
+  CXRK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, stream, ws, nparts, cols, out, alpha,
+                     accumulate);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}

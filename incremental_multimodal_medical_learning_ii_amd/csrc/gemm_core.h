@@ -1,0 +1,357 @@
+// fp32 MFMA GEMM mainloop shared by every dense / implicit-GEMM op of the path.
+//
+//   C[m][n] = epilogue( sum_k A(m,k) * B(k,n) )
+//
+// * v_mfma_f32_32x32x2_f32: exact fp32 (a k-ordered fmaf chain), 64 FLOP/clk/SIMD -> 157 TFLOP/s chip peak
+//   (MI355X_MICROARCH.md "Peak FP32 (matrix)").  fp32 keeps the 1e-3 parity bar of the north star with room.
+// * 256 threads = 4 waves, each wave owns a 64x64 output sub-tile = 2x2 MFMA tiles (64 accumulator VGPRs).
+//   Tile shapes: WMxWN waves -> (64*WM) x (64*WN); 2x2 = 128x128 (default), 4x1 = 256x64, 1x4 = 64x256.
+// * Operand tiles are staged global -> registers -> LDS as [k][idx] (idx contiguous, +4 pad) so the MFMA
+//   operand read is a conflict-free ds_read_b32 (32 consecutive dwords per half-wave); the next K-tile's global
+//   loads are issued before the MFMA block of the current one (register prefetch, one LDS buffer).
+// * "Loaders" turn an (idx, k) tile coordinate into global addresses: dense K-contiguous, dense idx-contiguous,
+//   and the three NHWC convolution gathers (im2col for fprop, strided-tap gather for dgrad, pixel gather for
+//   wgrad).  All of them load 16 B per lane.
+// * blockIdx -> tile mapping is XCD-aware: the 8 XCDs each walk their own M panels and visit all N tiles of a
+//   panel back to back, so the A panel is re-read from that XCD's L2 rather than from HBM.
+#pragma once
+#include "cxrk_common.h"
+
+namespace cxrk {
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+constexpr int LPAD = 4;
+
+struct EpiParams {
+  float* C; long ldc;
+  const float* bias;             // per column n, or null
+  const float* R; long ldr;      // residual added before the activation, or null
+  const float* aux; long ldaux;  // auxmode 1: v *= (aux > 0); auxmode 2: v *= gelu'(aux)
+  int auxmode;
+  float* C2; long ldc2;          // optional copy of the pre-activation value
+  int act;                       // 0 none, 1 relu, 2 gelu(erf)
+  float alpha;                   // scales the accumulator
+  long slab_stride;              // split-K: slab z is written at C + z*slab_stride (epilogue must be plain)
+};
+
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Loaders.  TILE = extent of the idx dimension in the block tile.  Every loader exposes
+//   P (host-filled parameters), init(P, idx0, tid), load(k0, v[NV]), store(S, v[NV]).
+// ---------------------------------------------------------------------------------------------------------------
+
+// X(idx, k) = ptr[idx*ld + k]   (k contiguous)
+template <int TILE>
+struct DenseKC {
+  static constexpr int NV = TILE / 32;
+  struct P { const float* ptr; long ld; int rows; int K; };
+  const float* rp[NV];
+  int k4, r0, K;
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    k4 = tid & 7; r0 = tid >> 3; K = p.K;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int row = idx0 + r0 + j * 32;
+      rp[j] = row < p.rows ? p.ptr + (long)row * p.ld : nullptr;
+    }
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
+    const int k = k0 + k4 * 4;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = (rp[j] != nullptr && k < K) ? *reinterpret_cast<const float4*>(rp[j] + k) : zero4();
+  }
+  __device__ __forceinline__ void store(float* S, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      float* d = S + (k4 * 4) * (TILE + LPAD) + r0 + j * 32;
+      d[0] = v[j].x; d[TILE + LPAD] = v[j].y; d[2 * (TILE + LPAD)] = v[j].z; d[3 * (TILE + LPAD)] = v[j].w;
+    }
+  }
+};
+
+// X(idx, k) = ptr[k*ld + idx]   (idx contiguous)
+template <int TILE>
+struct DenseMC {
+  static constexpr int NV = TILE / 32;
+  static constexpr int VPR = TILE / 4;          // float4 per k-row
+  static constexpr int RPP = NTHREADS / VPR;    // k-rows per pass
+  struct P { const float* ptr; long ld; int cols; int K; };
+  const float* base; long ld_;
+  int c4, kr0, K; bool ok;
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    c4 = tid % VPR; kr0 = tid / VPR; K = p.K; ld_ = p.ld;
+    ok = idx0 + c4 * 4 < p.cols;
+    base = p.ptr + idx0 + c4 * 4;
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int k = k0 + kr0 + j * RPP;
+      v[j] = (ok && k < K) ? *reinterpret_cast<const float4*>(base + (long)k * ld_) : zero4();
+    }
+  }
+  __device__ __forceinline__ void store(float* S, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      *reinterpret_cast<float4*>(S + (kr0 + j * RPP) * (TILE + LPAD) + c4 * 4) = v[j];
+  }
+};
+
+// NHWC geometry shared by the convolution gathers.
+struct ConvGeom {
+  int N, H, W, C;        // input  x[N][H][W][C]
+  int Ho, Wo, Ko;        // output y[N][Ho][Wo][Ko]
+  int R, S, stride, pad; // filter w[Ko][R][S][C]
+};
+
+// fprop A operand: idx = (n,ho,wo), k = (r,s,c) -> x[n][ho*st-pad+r][wo*st-pad+s][c]   (c contiguous)
+template <int TILE>
+struct ConvIm2colKC {
+  static constexpr int NV = TILE / 32;
+  struct P { const float* x; ConvGeom g; int rows; int K; };
+  long off[NV]; int hi0[NV], wi0[NV];
+  const float* x; int k4, r0, K, H, W, C, S;
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    k4 = tid & 7; r0 = tid >> 3; K = p.K; x = p.x; H = p.g.H; W = p.g.W; C = p.g.C; S = p.g.S;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int row = idx0 + r0 + j * 32;
+      if (row < p.rows) {
+        const int wo = row % p.g.Wo; const int t = row / p.g.Wo; const int ho = t % p.g.Ho; const int n = t / p.g.Ho;
+        hi0[j] = ho * p.g.stride - p.g.pad; wi0[j] = wo * p.g.stride - p.g.pad;
+        off[j] = (((long)n * H + hi0[j]) * W + wi0[j]) * C;
+      } else { hi0[j] = -(1 << 28); wi0[j] = 0; off[j] = 0; }
+    }
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
+    const int k = k0 + k4 * 4;
+    const int tap = k / C, c = k - tap * C;
+    const int r = tap / S, s = tap - r * S;
+    const long toff = ((long)r * W + s) * C + c;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int hi = hi0[j] + r, wi = wi0[j] + s;
+      const bool ok = (k < K) && ((unsigned)hi < (unsigned)H) && ((unsigned)wi < (unsigned)W);
+      v[j] = ok ? *reinterpret_cast<const float4*>(x + off[j] + toff) : zero4();
+    }
+  }
+  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      float* d = Sm + (k4 * 4) * (TILE + LPAD) + r0 + j * 32;
+      d[0] = v[j].x; d[TILE + LPAD] = v[j].y; d[2 * (TILE + LPAD)] = v[j].z; d[3 * (TILE + LPAD)] = v[j].w;
+    }
+  }
+};
+
+// dgrad A operand: idx = (n,hi,wi), k = (r,s,ko) -> dy[n][(hi+pad-r)/st][(wi+pad-s)/st][ko] when divisible & in range
+template <int TILE>
+struct ConvDgradKC {
+  static constexpr int NV = TILE / 32;
+  struct P { const float* dy; ConvGeom g; int rows; int K; };
+  long nbase[NV]; int hp[NV], wp[NV];
+  const float* dy; int k4, r0, K, Ho, Wo, Ko, S, st;
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    k4 = tid & 7; r0 = tid >> 3; K = p.K; dy = p.dy; Ho = p.g.Ho; Wo = p.g.Wo; Ko = p.g.Ko; S = p.g.S; st = p.g.stride;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int row = idx0 + r0 + j * 32;
+      if (row < p.rows) {
+        const int wi = row % p.g.W; const int t = row / p.g.W; const int hi = t % p.g.H; const int n = t / p.g.H;
+        hp[j] = hi + p.g.pad; wp[j] = wi + p.g.pad; nbase[j] = (long)n * Ho * Wo * Ko;
+      } else { hp[j] = -(1 << 28); wp[j] = 0; nbase[j] = 0; }
+    }
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
+    const int k = k0 + k4 * 4;
+    const int tap = k / Ko, ko = k - tap * Ko;
+    const int r = tap / S, s = tap - r * S;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int hn = hp[j] - r, wn = wp[j] - s;
+      bool ok = (k < K) && hn >= 0 && wn >= 0;
+      int ho = hn, wo = wn;
+      if (st == 2) { ok = ok && ((hn & 1) == 0) && ((wn & 1) == 0); ho = hn >> 1; wo = wn >> 1; }
+      ok = ok && ho < Ho && wo < Wo;
+      v[j] = ok ? *reinterpret_cast<const float4*>(dy + nbase[j] + ((long)ho * Wo + wo) * Ko + ko) : zero4();
+    }
+  }
+  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      float* d = Sm + (k4 * 4) * (TILE + LPAD) + r0 + j * 32;
+      d[0] = v[j].x; d[TILE + LPAD] = v[j].y; d[2 * (TILE + LPAD)] = v[j].z; d[3 * (TILE + LPAD)] = v[j].w;
+    }
+  }
+};
+
+// dgrad B operand: k = (r,s,ko), idx = c -> w[ko][r][s][c]   (c contiguous)
+template <int TILE>
+struct ConvFilterMC {
+  static constexpr int NV = TILE / 32;
+  static constexpr int VPR = TILE / 4;
+  static constexpr int RPP = NTHREADS / VPR;
+  struct P { const float* w; ConvGeom g; int cols; int K; };
+  const float* base; int c4, kr0, K, Ko, C; long RSC; bool ok;
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    c4 = tid % VPR; kr0 = tid / VPR; K = p.K; Ko = p.g.Ko; C = p.g.C; RSC = (long)p.g.R * p.g.S * p.g.C;
+    ok = idx0 + c4 * 4 < p.cols; base = p.w + idx0 + c4 * 4;
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int k = k0 + kr0 + j * RPP;
+      const int tap = k / Ko, ko = k - tap * Ko;
+      v[j] = (ok && k < K) ? *reinterpret_cast<const float4*>(base + (long)ko * RSC + (long)tap * C) : zero4();
+    }
+  }
+  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      *reinterpret_cast<float4*>(Sm + (kr0 + j * RPP) * (TILE + LPAD) + c4 * 4) = v[j];
+  }
+};
+
+// wgrad B operand: k = (n,ho,wo), idx = (r,s,c) -> x[n][ho*st-pad+r][wo*st-pad+s][c]   (c contiguous)
+template <int TILE>
+struct ConvIm2colMC {
+  static constexpr int NV = TILE / 32;
+  static constexpr int VPR = TILE / 4;
+  static constexpr int RPP = NTHREADS / VPR;
+  struct P { const float* x; ConvGeom g; int cols; int K; };
+  const float* x; int c4, kr0, K, H, W, C, Ho, Wo, st, dh, dw; long coff; bool ok;
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    c4 = tid % VPR; kr0 = tid / VPR; K = p.K; x = p.x; H = p.g.H; W = p.g.W; C = p.g.C; Ho = p.g.Ho; Wo = p.g.Wo; st = p.g.stride;
+    const int col = idx0 + c4 * 4;
+    ok = col < p.cols;
+    const int tap = col / C, c = col - tap * C;
+    const int r = tap / p.g.S, s = tap - r * p.g.S;
+    dh = r - p.g.pad; dw = s - p.g.pad; coff = c;
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int k = k0 + kr0 + j * RPP;
+      const int wo = k % Wo; const int t = k / Wo; const int ho = t % Ho; const int n = t / Ho;
+      const int hi = ho * st + dh, wi = wo * st + dw;
+      const bool in = ok && (k < K) && ((unsigned)hi < (unsigned)H) && ((unsigned)wi < (unsigned)W);
+      v[j] = in ? *reinterpret_cast<const float4*>(x + (((long)n * H + hi) * W + wi) * C + coff) : zero4();
+    }
+  }
+  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      *reinterpret_cast<float4*>(Sm + (kr0 + j * RPP) * (TILE + LPAD) + c4 * 4) = v[j];
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Kernel
+// ---------------------------------------------------------------------------------------------------------------
+template <class LA, class LB, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS, 3) void gemm_f32_kernel(typename LA::P pa, typename LB::P pb, EpiParams ep,
+                                                            int M, int N, int K, int nMt, int nNt, int kchunk) {
+  constexpr int BM = WM * 64, BN = WN * 64;
+  __shared__ __attribute__((aligned(16))) float As[BK * (BM + LPAD)];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * (BN + LPAD)];
+
+  // XCD-aware tile mapping: blocks b and b+8 share an XCD (round-robin dispatch; speed only, never correctness).
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q = b >> 3;
+  const int nt = q % nNt;
+  const int mt = (q / nNt) * 8 + xcd;
+  if (mt >= nMt) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int z = blockIdx.y;
+  const int kbeg = z * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+
+  LA la; LB lb;
+  la.init(pa, m0, tid);
+  lb.init(pb, n0, tid);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 ra[LA::NV], rb[LB::NV];
+  if (kbeg < kend) { la.load(kbeg, ra); lb.load(kbeg, rb); }
+
+  const float* Ap = As + wm * 64 + r;
+  const float* Bp = Bs + wn * 64 + r;
+
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    la.store(As, ra);
+    lb.store(Bs, rb);
+    __syncthreads();
+    if (k0 + BK < kend) { la.load(k0 + BK, ra); lb.load(k0 + BK, rb); }
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int krow = 2 * kk + h;
+      const float a0 = Ap[krow * (BM + LPAD)];
+      const float a1 = Ap[krow * (BM + LPAD) + 32];
+      const float b0 = Bp[krow * (BN + LPAD)];
+      const float b1 = Bp[krow * (BN + LPAD) + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // Epilogue.  C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  float* C = ep.C + (long)z * ep.slab_stride;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + r;
+    if (col >= N) continue;
+    const float bv = ep.bias ? ep.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row >= M) continue;
+        float v = ep.alpha * acc[i][j][e] + bv;
+        if (ep.R) v += ep.R[(long)row * ep.ldr + col];
+        if (ep.C2) ep.C2[(long)row * ep.ldc2 + col] = v;
+        if (ep.act == 1) v = fmaxf(v, 0.f);
+        else if (ep.act == 2) v = gelu_erf(v);
+        if (ep.auxmode == 1) v = ep.aux[(long)row * ep.ldaux + col] > 0.f ? v : 0.f;
+        else if (ep.auxmode == 2) v *= gelu_erf_grad(ep.aux[(long)row * ep.ldaux + col]);
+        C[(long)row * ep.ldc + col] = v;
+      }
+    }
+  }
+}
+
+// Host launcher.  splitk > 1 writes plain partial slabs (caller reduces them).
+template <class LA, class LB, int WM, int WN>
+static int launch_gemm(const typename LA::P& pa, const typename LB::P& pb, const EpiParams& ep, int M, int N, int K,
+                       int splitk, hipStream_t stream) {
+  constexpr int BM = WM * 64, BN = WN * 64;
+  if (M <= 0 || N <= 0 || K <= 0) return CXRK_ERR_ARG;
+  const int nMt = ceil_div(M, BM), nNt = ceil_div(N, BN);
+  const int nMt8 = ceil_div(nMt, 8) * 8;
+  int kchunk = K;
+  if (splitk > 1) { kchunk = ceil_div(ceil_div(K, splitk), BK) * BK; splitk = ceil_div(K, kchunk); }
+  else splitk = 1;
+  dim3 grid((unsigned)(nMt8 * nNt), (unsigned)splitk, 1);
+  hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, ep, M, N, K, nMt, nNt, kchunk);
+  CXRK_LAUNCH_CHECK();
+  return splitk;  // >= 1: number of slabs actually written
+}
+
+}  // namespace cxrk

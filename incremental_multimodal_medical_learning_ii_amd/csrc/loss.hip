@@ -1,0 +1,326 @@
+// Similarity + loss heads.
+//  * L2 row normalisation fwd/bwd (F.normalize semantics, eps on the norm)
+//  * InfoNCE pieces on a materialised logits block S[B][Bg] (the logits GEMMs run on the shared MFMA mainloop):
+//    row log-sum-exp + diagonal pick, and the in-place softmax-gradient transform
+//  * torchmetrics-style pairwise cosine fwd/bwd (reference Trainer.myCosineSimilarity, Trainer.py:1682-1704)
+//  * pos-neg logits + BCE-with-logits(mean) fwd+bwd in one pass (Trainer.py:575-583, ZERO_JOINT_BOUNDS.py:36)
+//  * eval scoring (Trainer.py:797-837)
+#include "cxrk.h"
+#include "cxrk_common.h"
+
+using namespace cxrk;
+
+namespace {
+
+// one wave per row; D <= 64*8
+constexpr int NV = 8;
+
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, long rows, int D, float eps,
+                                                         float* __restrict__ xhat, float* __restrict__ norm) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float v[NV]; float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { const int c = lane + i * 64; v[i] = c < D ? x[row * D + c] : 0.f; q += v[i] * v[i]; }
+  const float n = sqrtf(wave_sum(q));
+  const float inv = 1.0f / fmaxf(n, eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { const int c = lane + i * 64; if (c < D) xhat[row * D + c] = v[i] * inv; }
+  if (lane == 0 && norm) norm[row] = fmaxf(n, eps);
+}
+
+// dx = (dxhat - xhat * <xhat, dxhat>) / norm
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dxhat, const float* __restrict__ xhat,
+                                                         const float* __restrict__ norm, long rows, int D,
+                                                         float* __restrict__ dx) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float g[NV], h[NV]; float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    g[i] = c < D ? dxhat[row * D + c] : 0.f; h[i] = c < D ? xhat[row * D + c] : 0.f; dot += g[i] * h[i];
+  }
+  dot = wave_sum(dot);
+  const float inv = 1.0f / norm[row];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { const int c = lane + i * 64; if (c < D) dx[row * D + c] = (g[i] - h[i] * dot) * inv; }
+}
+
+// lse[i] = log sum_j exp(S[i][j]); diag[i] = S[i][diag_off + i]; one 256-thread block per row.
+__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ S, long ld, int cols, int diag_off,
+                                                      float* __restrict__ lse, float* __restrict__ diag) {
+  __shared__ float sh[16];
+  const long row = blockIdx.x;
+  const float* s = S + row * ld;
+  float m = -INFINITY;
+  for (int j = threadIdx.x; j < cols; j += 256) m = fmaxf(m, s[j]);
+  m = block_max(m, sh);
+  float sum = 0.f;
+  for (int j = threadIdx.x; j < cols; j += 256) sum += expf(s[j] - m);
+  sum = block_sum(sum, sh);
+  if (threadIdx.x == 0) { lse[row] = m + logf(sum); diag[row] = s[diag_off + row]; }
+}
+
+// G[i][j] = exp(S[i][j]-lse_row[i]) + exp(S[i][j]-lse_col[j]) - 2*[j == diag_off+i], in place.
+__global__ void infonce_grad_kernel(float* __restrict__ S, long ld, long rows, int cols, int diag_off,
+                                    const float* __restrict__ lse_row, const float* __restrict__ lse_col) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * cols) return;
+  const long i = t / cols; const int j = (int)(t - i * cols);
+  const float s = S[i * ld + j];
+  float g = expf(s - lse_row[i]) + expf(s - lse_col[j]);
+  if (j == diag_off + (int)i) g -= 2.f;
+  S[i * ld + j] = g;
+}
+
+// sum_i (lse[i] - diag[i]) * scale  -> out[0] (+= when accumulate); single block.
+__global__ void lse_loss_kernel(const float* __restrict__ lse, const float* __restrict__ diag, int n, float scale,
+                                float* __restrict__ out, int accumulate) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += lse[i] - diag[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s * scale : s * scale;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pairwise cosine: cos[i][p] = <x_i, y_p> / (|x_i| |y_p|)  (no epsilon: torchmetrics semantics)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pairwise_cosine_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                  long B, int P, int D, float* __restrict__ cosv,
+                                                                  float* __restrict__ xnorm, float* __restrict__ ynorm) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const int lane = threadIdx.x & 63;
+  float v[NV]; float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { const int c = lane + i * 64; v[i] = c < D ? x[row * D + c] : 0.f; q += v[i] * v[i]; }
+  const float xn = sqrtf(wave_sum(q));
+  if (lane == 0) xnorm[row] = xn;
+  for (int p = 0; p < P; ++p) {
+    float d = 0.f, yy = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + i * 64;
+      const float w = c < D ? y[(long)p * D + c] : 0.f;
+      d += v[i] * w; yy += w * w;
+    }
+    d = wave_sum(d); yy = sqrtf(wave_sum(yy));
+    if (lane == 0) { cosv[row * P + p] = (d / xn) / yy; if (row == 0) ynorm[p] = yy; }
+  }
+}
+
+// dx_i = sum_p dc[i][p] * (yhat_p - cos*xhat_i)/|x_i| ; dy partial[blk][p] = sum_{i in blk} dc * (xhat_i - cos*yhat_p)/|y_p|
+__global__ __launch_bounds__(256) void pairwise_cosine_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                  const float* __restrict__ cosv, const float* __restrict__ dcos,
+                                                                  const float* __restrict__ xnorm, const float* __restrict__ ynorm,
+                                                                  long B, int P, int D, int rows_per, float* __restrict__ dx,
+                                                                  float* __restrict__ dy_part) {
+  extern __shared__ float sm[];  // [4 waves][P][D]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* mine = sm + (long)w * P * D;
+  for (int i = lane; i < P * D; i += 64) mine[i] = 0.f;
+  const long r0 = (long)blockIdx.x * rows_per, r1 = min(B, r0 + rows_per);
+  for (long row = r0 + w; row < r1; row += 4) {
+    float xh[NV], acc[NV];
+    const float ixn = 1.0f / xnorm[row];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { const int c = lane + i * 64; xh[i] = c < D ? x[row * D + c] * ixn : 0.f; acc[i] = 0.f; }
+    for (int p = 0; p < P; ++p) {
+      const float dc = dcos[row * P + p], cs = cosv[row * P + p];
+      const float iyn = 1.0f / ynorm[p];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < D) {
+          const float yh = y[(long)p * D + c] * iyn;
+          acc[i] += dc * (yh - cs * xh[i]);
+          mine[p * D + c] += dc * (xh[i] - cs * yh) * iyn;
+        }
+      }
+    }
+    if (dx) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { const int c = lane + i * 64; if (c < D) dx[row * D + c] = acc[i] * ixn; }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < P * D; i += 256)
+    dy_part[(long)blockIdx.x * P * D + i] = (sm[i] + sm[(long)P * D + i]) + (sm[2L * P * D + i] + sm[3L * P * D + i]);
+}
+__global__ void partial_reduce_kernel(const float* __restrict__ part, int nparts, long n, float* __restrict__ out, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(long)p * n + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+// logits[i][c] = cos[i][2c] - cos[i][2c+1] (diff) or cos[i][2c]; loss = mean BCEWithLogits; dcos = dloss/dcos.
+// Single-pass: per-block partial loss sums, finished by lse-style final kernel.
+__global__ __launch_bounds__(256) void bce_posneg_kernel(const float* __restrict__ cosv, const float* __restrict__ labels,
+                                                         long B, int C, int ldlab, int diff, float* __restrict__ logits,
+                                                         float* __restrict__ dcos, float* __restrict__ part) {
+  __shared__ float sh[16];
+  const long n = B * C;
+  const float invn = 1.0f / (float)n;
+  float ls = 0.f;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+    const long i = t / C; const int c = (int)(t - i * C);
+    const float cp = cosv[i * 2 * C + 2 * c], cn = cosv[i * 2 * C + 2 * c + 1];
+    const float z = diff ? cp - cn : cp;
+    const float yv = labels[i * ldlab + c];
+    // max(z,0) - z*y + log1p(exp(-|z|))
+    ls += fmaxf(z, 0.f) - z * yv + log1pf(expf(-fabsf(z)));
+    if (logits) logits[t] = z;
+    if (dcos) {
+      const float sg = 1.0f / (1.0f + expf(-z));
+      const float dz = (sg - yv) * invn;
+      dcos[i * 2 * C + 2 * c] = dz;
+      dcos[i * 2 * C + 2 * c + 1] = diff ? -dz : 0.f;
+    }
+  }
+  ls = block_sum(ls, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = ls;
+}
+__global__ void scalar_reduce_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ out) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+// Trainer.val scoring: score = (pos+1)/2 or (pos-neg+2)/4; pred = argmax([neg,pos]) ; logit diff kept for the BCE log.
+__global__ void eval_score_kernel(const float* __restrict__ cosv, long B, int C, int pred_diff, float* __restrict__ score,
+                                  float* __restrict__ pred) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * C) return;
+  const long i = t / C; const int c = (int)(t - i * C);
+  const float cp = cosv[i * 2 * C + 2 * c], cn = cosv[i * 2 * C + 2 * c + 1];
+  score[t] = pred_diff ? (cp - cn + 2.f) * 0.25f : (cp + 1.f) * 0.5f;
+  pred[t] = cp > cn ? 1.f : 0.f;
+}
+
+// prompt-group mean: out[g][d] = mean_n in[g][n][d]  and its backward
+__global__ void group_mean_fwd_kernel(const float* __restrict__ in, int G, int n, int D, float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= G * D) return;
+  const int g = t / D, d = t - g * D;
+  float s = 0.f;
+  for (int k = 0; k < n; ++k) s += in[((long)g * n + k) * D + d];
+  out[t] = s / (float)n;
+}
+__global__ void group_mean_bwd_kernel(const float* __restrict__ dout, int G, int n, int D, float* __restrict__ din) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= G * n * D) return;
+  const int d = t % D; const int g = t / (n * D);
+  din[t] = dout[g * D + d] / (float)n;
+}
+
+}  // namespace
+
+extern "C" int cxrk_l2norm_fwd(const float* x, long rows, int D, float eps, float* xhat, float* norm, hipStream_t stream) {
+  CXRK_CHECK_ARG(x && xhat && rows > 0 && D > 0 && D <= 64 * NV);
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, rows, D, eps, xhat, norm);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+extern "C" int cxrk_l2norm_bwd(const float* dxhat, const float* xhat, const float* norm, long rows, int D, float* dx,
+                               hipStream_t stream) {
+  CXRK_CHECK_ARG(dxhat && xhat && norm && dx && rows > 0 && D > 0 && D <= 64 * NV);
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, dxhat, xhat, norm, rows, D, dx);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+
+extern "C" int cxrk_infonce_row_lse(const float* S, long ld, int rows, int cols, int diag_off, float* lse, float* diag,
+                                    float* loss_out, float loss_scale, int loss_accumulate, hipStream_t stream) {
+  CXRK_CHECK_ARG(S && lse && diag && rows > 0 && cols > 0 && diag_off >= 0 && diag_off + rows <= cols);
+  hipLaunchKernelGGL(row_lse_kernel, dim3(rows), dim3(256), 0, stream, S, ld, cols, diag_off, lse, diag);
+  CXRK_LAUNCH_CHECK();
+  if (loss_out) {
+    hipLaunchKernelGGL(lse_loss_kernel, dim3(1), dim3(256), 0, stream, lse, diag, rows, loss_scale, loss_out, loss_accumulate);
+    CXRK_LAUNCH_CHECK();
+  }
+  return CXRK_OK;
+}
+
+extern "C" int cxrk_infonce_grad_inplace(float* S, long ld, int rows, int cols, int diag_off, const float* lse_row,
+                                         const float* lse_col, hipStream_t stream) {
+  CXRK_CHECK_ARG(S && lse_row && lse_col && rows > 0 && cols > 0);
+  const long n = (long)rows * cols;
+  hipLaunchKernelGGL(infonce_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, ld, (long)rows, cols,
+                     diag_off, lse_row, lse_col);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+
+extern "C" int cxrk_pairwise_cosine_fwd(const float* x, const float* y, long B, int P, int D, float* cosv, float* xnorm,
+                                        float* ynorm, hipStream_t stream) {
+  CXRK_CHECK_ARG(x && y && cosv && xnorm && ynorm && B > 0 && P > 0 && D > 0 && D <= 64 * NV);
+  hipLaunchKernelGGL(pairwise_cosine_fwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, x, y, B, P, D, cosv, xnorm, ynorm);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+
+static int cos_bwd_blocks(long B) { long nb = (B + 63) / 64; if (nb > 512) nb = 512; if (nb < 1) nb = 1; return (int)nb; }
+extern "C" size_t cxrk_pairwise_cosine_bwd_ws_bytes(long B, int P, int D) { return (size_t)cos_bwd_blocks(B) * P * D * sizeof(float); }
+
+extern "C" int cxrk_pairwise_cosine_bwd(const float* x, const float* y, const float* cosv, const float* dcos,
+                                        const float* xnorm, const float* ynorm, long B, int P, int D, float* dx, float* dy,
+                                        int accumulate_dy, float* ws, size_t ws_bytes, hipStream_t stream) {
+  CXRK_CHECK_ARG(x && y && cosv && dcos && xnorm && ynorm && dy && B > 0 && P > 0 && D > 0 && D <= 64 * NV);
+  const size_t sh = (size_t)4 * P * D * sizeof(float);
+  if (sh > 64 * 1024) return CXRK_ERR_UNSUPPORTED;
+  int nb = cos_bwd_blocks(B);
+  if (ws == nullptr || ws_bytes < (size_t)nb * P * D * sizeof(float)) return CXRK_ERR_WS;
+  const int rows_per = (int)((B + nb - 1) / nb);
+  nb = (int)((B + rows_per - 1) / rows_per);
+  hipLaunchKernelGGL(pairwise_cosine_bwd_kernel, dim3(nb), dim3(256), sh, stream, x, y, cosv, dcos, xnorm, ynorm, B, P, D,
+                     rows_per, dx, ws);
+  CXRK_LAUNCH_CHECK();
+  const long n = (long)P * D;
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ws, nb, n, dy, accumulate_dy);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+
+extern "C" size_t cxrk_bce_posneg_ws_bytes(void) { return 256 * sizeof(float); }
+
+extern "C" int cxrk_bce_posneg_fwd_bwd(const float* cosv, const float* labels, long B, int C, int ldlab, int diff,
+                                       float* logits, float* dcos, float* loss, float* ws, size_t ws_bytes,
+                                       hipStream_t stream) {
+  CXRK_CHECK_ARG(cosv && labels && loss && B > 0 && C > 0 && ldlab >= C);
+  if (ws == nullptr || ws_bytes < 256 * sizeof(float)) return CXRK_ERR_WS;
+  long nb = (B * C + 255) / 256; if (nb > 256) nb = 256;
+  hipLaunchKernelGGL(bce_posneg_kernel, dim3((unsigned)nb), dim3(256), 0, stream, cosv, labels, B, C, ldlab, diff, logits, dcos, ws);
+  CXRK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scalar_reduce_kernel, dim3(1), dim3(256), 0, stream, ws, (int)nb, 1.0f / (float)(B * C), loss);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+
+extern "C" int cxrk_eval_score(const float* cosv, long B, int C, int pred_diff, float* score, float* pred, hipStream_t stream) {
+  CXRK_CHECK_ARG(cosv && score && pred && B > 0 && C > 0);
+  const long n = B * C;
+  hipLaunchKernelGGL(eval_score_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cosv, B, C, pred_diff, score, pred);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+
+extern "C" int cxrk_group_mean_fwd(const float* in, int G, int n, int D, float* out, hipStream_t stream) {
+  CXRK_CHECK_ARG(in && out && G > 0 && n > 0 && D > 0);
+  hipLaunchKernelGGL(group_mean_fwd_kernel, dim3((unsigned)((G * D + 255) / 256)), dim3(256), 0, stream, in, G, n, D, out);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+extern "C" int cxrk_group_mean_bwd(const float* dout, int G, int n, int D, float* din, hipStream_t stream) {
+  CXRK_CHECK_ARG(dout && din && G > 0 && n > 0 && D > 0);
+  hipLaunchKernelGGL(group_mean_bwd_kernel, dim3((unsigned)((G * n * D + 255) / 256)), dim3(256), 0, stream, dout, G, n, D, din);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}

@@ -1,0 +1,463 @@
+"""Tensor-level wrappers over the cxrk C-ABI (one Python function per entry point family).
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the current HIP stream.  Every function
+checks that its operands are CUDA(HIP) fp32 tensors laid out as the kernel expects and raises otherwise; nothing
+falls back to torch arithmetic.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+AUX_NONE, AUX_RELU_MASK, AUX_GELU_GRAD = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError(f"{name}: expected a tensor on the GPU (the cxrk path has no CPU fallback), got "
+                         f"{type(t).__name__} on {getattr(t, 'device', None)}")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t
+
+
+def _rowmajor2d(t: torch.Tensor, name: str) -> Tuple[torch.Tensor, int]:
+    _chk(t, name)
+    if t.dim() != 2:
+        raise ValueError(f"{name}: expected 2-D, got shape {tuple(t.shape)}")
+    if t.shape[1] != 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
+
+
+class _Workspace:
+    """Grow-on-demand scratch buffer per device; reuse is safe because all kernels run stream-ordered."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        key = (device.type, device.index)
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() * 4 < nbytes:
+            n = max(int(nbytes * 1.25) // 4 + 64, 1 << 20)
+            buf = torch.empty(n, dtype=torch.float32, device=device)
+            self.bufs[key] = buf
+        return buf
+
+
+_ws = _Workspace()
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    return _ws.get(nbytes, device)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# GEMM family
+# ----------------------------------------------------------------------------------------------------------------
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, trans_a: bool, trans_b: bool,
+         bias=None, residual=None, aux=None, auxmode: int = 0, preact_out=None, act: int = 0, alpha: float = 1.0,
+         accumulate: bool = False, splitk: int = 1) -> torch.Tensor:
+    lib = _lib.load()
+    a, lda = _rowmajor2d(a, "gemm.a")
+    b, ldb = _rowmajor2d(b, "gemm.b")
+    _chk(out, "gemm.out")
+    if out.dim() != 2 or out.stride(1) != 1:
+        raise ValueError("gemm.out must be a row-major 2-D tensor")
+    ldc = out.stride(0)
+    ldr = ldaux = ldc2 = 0
+    if residual is not None:
+        residual, ldr = _rowmajor2d(residual, "gemm.residual")
+    if aux is not None:
+        aux, ldaux = _rowmajor2d(aux, "gemm.aux")
+    if preact_out is not None:
+        _chk(preact_out, "gemm.preact_out")
+        ldc2 = preact_out.stride(0)
+    if bias is not None:
+        _chk(bias, "gemm.bias")
+        if bias.numel() != N or not bias.is_contiguous():
+            raise ValueError("gemm.bias must be contiguous with N elements")
+    ws = None
+    wsb = 0
+    if splitk > 1:
+        wsb = lib.cxrk_gemm_splitk_ws_bytes(M, N, splitk)
+        ws = workspace(wsb, out.device)
+        wsb = ws.numel() * 4
+    rc = lib.cxrk_gemm_f32(int(trans_a), int(trans_b), M, N, K, _p(a), lda, _p(b), ldb, _p(out), ldc, _p(bias),
+                           _p(residual), ldr, _p(aux), ldaux, auxmode, _p(preact_out), ldc2, act, float(alpha),
+                           int(accumulate), int(splitk), _p(ws), wsb, _stream())
+    check(rc, f"cxrk_gemm_f32(M={M},N={N},K={K},tA={trans_a},tB={trans_b})")
+    return out
+
+
+def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias=None, act: int = 0, residual=None, preact_out=None,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y[M,N] = act(x[M,K] @ w[N,K]^T + bias + residual)."""
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"linear_fwd: x is [{M},{K}] but w is {tuple(w.shape)}")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    return gemm(x, w, out, M, N, K, False, True, bias=bias, residual=residual, preact_out=preact_out, act=act)
+
+
+def linear_bwd_data(dy: torch.Tensor, w: torch.Tensor, aux=None, auxmode: int = 0, residual=None,
+                    out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """dx[M,K] = (dy[M,N] @ w[N,K] + residual) (* mask/gelu'(aux))."""
+    M, N = dy.shape
+    K = w.shape[1]
+    if out is None:
+        out = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+    return gemm(dy, w, out, M, K, N, False, False, aux=aux, auxmode=auxmode, residual=residual, accumulate=accumulate)
+
+
+def _wgrad_splitk(n_out: int, n_in: int, rows: int) -> int:
+    tiles = ((n_out + 127) // 128) * ((n_in + 127) // 128)
+    want = max(1, (1536 + tiles - 1) // tiles)
+    return int(max(1, min(want, rows // 256, 512)))
+
+
+def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    """dw[N,K] (+)= dy[M,N]^T @ x[M,K]  (deterministic split-K over M)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    sk = _wgrad_splitk(N, K, M)
+    if sk > 1:
+        return gemm(dy, x, dw, N, K, M, True, False, accumulate=accumulate, splitk=sk)
+    return gemm(dy, x, dw, N, K, M, True, False, accumulate=accumulate)
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:
+    lib = _lib.load()
+    x, ldx = _rowmajor2d(x, "colsum.x")
+    _chk(out, "colsum.out")
+    rows, cols = x.shape
+    wsb = lib.cxrk_colsum_ws_bytes(rows, cols)
+    ws = workspace(wsb, x.device)
+    check(lib.cxrk_colsum(_p(x), ldx, rows, cols, _p(out), float(alpha), int(accumulate), _p(ws), ws.numel() * 4,
+                          _stream()), "cxrk_colsum")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# image encoder pieces (NHWC)
+# ----------------------------------------------------------------------------------------------------------------
+
+def bn_fold(w, gamma, beta, rmean, rvar, eps, Ko, taps, C, Cpad, w_scaled, scale, shift, rstd):
+    lib = _lib.load()
+    for n, t in (("w", w), ("gamma", gamma), ("beta", beta), ("rmean", rmean), ("rvar", rvar)):
+        _chk(t, "bn_fold." + n)
+    check(lib.cxrk_bn_fold(_p(w), _p(gamma), _p(beta), _p(rmean), _p(rvar), float(eps), Ko, taps, C, Cpad,
+                           _p(w_scaled), _p(scale), _p(shift), _p(rstd), _stream()), "cxrk_bn_fold")
+
+
+def conv_fwd(x, w_scaled, shift, residual, y, N, H, W, C, Ko, R, S, stride, pad, relu):
+    lib = _lib.load()
+    check(lib.cxrk_conv_bn_act_fwd(_p(_chk(x, "conv.x")), _p(w_scaled), _p(shift), _p(residual), _p(y), N, H, W, C, Ko,
+                                   R, S, stride, pad, int(relu), _stream()),
+          f"cxrk_conv_bn_act_fwd(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
+    return y
+
+
+def conv_bwd_data(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R, S, stride, pad):
+    lib = _lib.load()
+    check(lib.cxrk_conv_bn_act_bwd_data(_p(_chk(dy, "conv.dy")), _p(w_scaled), _p(residual), _p(relu_src), _p(dx), N, H,
+                                        W, C, Ko, R, S, stride, pad, _stream()),
+          f"cxrk_conv_bn_act_bwd_data(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
+    return dx
+
+
+def conv_bwd_params(x, dy, w, scale, rstd, rmean, sumdy, dw, dgamma, dbeta, accumulate, N, H, W, C, Cpad, Ko, R, S,
+                    stride, pad):
+    lib = _lib.load()
+    wsb = lib.cxrk_conv_wgrad_ws_bytes(N, H, W, Cpad, Ko, R, S, stride, pad)
+    ws = workspace(wsb, x.device)
+    check(lib.cxrk_conv_bn_act_bwd_params(_p(_chk(x, "conv.x")), _p(_chk(dy, "conv.dy")), _p(w), _p(scale), _p(rstd),
+                                          _p(rmean), _p(sumdy), _p(dw), _p(dgamma), _p(dbeta), int(accumulate), N, H, W,
+                                          C, Cpad, Ko, R, S, stride, pad, _p(ws), ws.numel() * 4, _stream()),
+          f"cxrk_conv_bn_act_bwd_params(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
+
+
+def nchw_to_nhwc(x: torch.Tensor, cpad: int) -> torch.Tensor:
+    lib = _lib.load()
+    _chk(x, "nchw_to_nhwc.x")
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    y = torch.empty(N, H, W, cpad, dtype=torch.float32, device=x.device)
+    check(lib.cxrk_nchw_to_nhwc(_p(x), _p(y), N, C, H, W, cpad, _stream()), "cxrk_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _chk(x, "nhwc_to_nchw.x")
+    N, H, W, C = x.shape
+    y = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)
+    check(lib.cxrk_nhwc_to_nchw(_p(x), _p(y), N, C, H, W, _stream()), "cxrk_nhwc_to_nchw")
+    return y
+
+
+def maxpool_fwd(x: torch.Tensor):
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(N, Ho, Wo, C, dtype=torch.float32, device=x.device)
+    idx = torch.empty(N, Ho, Wo, C, dtype=torch.uint8, device=x.device)
+    check(lib.cxrk_maxpool_fwd(_p(_chk(x, "maxpool.x")), _p(y), _p(idx), N, H, W, C, _stream()), "cxrk_maxpool_fwd")
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, x, relu_mask: bool):
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    check(lib.cxrk_maxpool_bwd(_p(_chk(dy, "maxpool.dy")), _p(idx), _p(x), _p(dx), N, H, W, C, int(relu_mask), _stream()),
+          "cxrk_maxpool_bwd")
+    return dx
+
+
+def spatial_mean_fwd(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    N, Pn, C = x.shape
+    y = torch.empty(N, C, dtype=torch.float32, device=x.device)
+    check(lib.cxrk_spatial_mean_fwd(_p(_chk(x, "spatial_mean.x")), _p(y), N, Pn, C, _stream()), "cxrk_spatial_mean_fwd")
+    return y
+
+
+def spatial_mean_bwd(dy: torch.Tensor, Pn: int) -> torch.Tensor:
+    lib = _lib.load()
+    N, C = dy.shape
+    dx = torch.empty(N, Pn, C, dtype=torch.float32, device=dy.device)
+    check(lib.cxrk_spatial_mean_bwd(_p(_chk(dy.contiguous(), "spatial_mean.dy")), _p(dx), N, Pn, C, _stream()),
+          "cxrk_spatial_mean_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# text encoder pieces
+# ----------------------------------------------------------------------------------------------------------------
+
+def embed_ln_fwd(ids, word, pos, type_row, gamma, beta, eps, L):
+    lib = _lib.load()
+    _chk(ids, "embed.ids", torch.int64)
+    ids = ids.contiguous()
+    T = ids.numel()
+    H = word.shape[1]
+    y = torch.empty(T, H, dtype=torch.float32, device=word.device)
+    xhat = torch.empty_like(y)
+    rstd = torch.empty(T, dtype=torch.float32, device=word.device)
+    check(lib.cxrk_embed_ln_fwd(_p(ids), _p(_chk(word, "embed.word")), _p(pos), _p(type_row), _p(gamma), _p(beta),
+                                float(eps), T, L, H, _p(y), _p(xhat), _p(rstd), _stream()), "cxrk_embed_ln_fwd")
+    return y, xhat, rstd
+
+
+def residual_ln_fwd(x, res, gamma, beta, eps, save: bool = True):
+    lib = _lib.load()
+    rows, H = x.shape
+    y = torch.empty_like(x)
+    xhat = torch.empty_like(x) if save else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
+    check(lib.cxrk_residual_ln_fwd(_p(_chk(x, "ln.x")), _p(res), _p(gamma), _p(beta), float(eps), rows, H, _p(y),
+                                   _p(xhat), _p(rstd), _stream()), "cxrk_residual_ln_fwd")
+    return y, xhat, rstd
+
+
+def residual_ln_bwd(dy, xhat, rstd, gamma, dgamma, dbeta, dx_add=None, accumulate: bool = False, out=None):
+    lib = _lib.load()
+    rows, H = dy.shape
+    dx = torch.empty_like(dy) if out is None else out
+    wsb = lib.cxrk_residual_ln_bwd_ws_bytes(rows, H)
+    ws = workspace(wsb, dy.device)
+    check(lib.cxrk_residual_ln_bwd(_p(_chk(dy, "ln.dy")), _p(xhat), _p(rstd), _p(gamma), rows, H, _p(dx_add), _p(dx),
+                                   _p(dgamma), _p(dbeta), int(accumulate), _p(ws), ws.numel() * 4, _stream()),
+          "cxrk_residual_ln_bwd")
+    return dx
+
+
+def attn_fwd(qkv, mask, B, L, nH, dH, save_probs: bool = True):
+    lib = _lib.load()
+    ctx = torch.empty(B * L, nH * dH, dtype=torch.float32, device=qkv.device)
+    probs = torch.empty(B, nH, L, L, dtype=torch.float32, device=qkv.device) if save_probs else None
+    if mask is not None:
+        _chk(mask, "attn.mask", torch.int64)
+    check(lib.cxrk_attn_fwd(_p(_chk(qkv, "attn.qkv")), _p(mask), B, L, nH, dH, _p(ctx), _p(probs), _stream()),
+          f"cxrk_attn_fwd(B={B},L={L},nH={nH},dH={dH})")
+    return ctx, probs
+
+
+def attn_bwd(qkv, probs, dctx, B, L, nH, dH):
+    lib = _lib.load()
+    dqkv = torch.empty_like(qkv)
+    check(lib.cxrk_attn_bwd(_p(qkv), _p(probs), _p(_chk(dctx, "attn.dctx")), B, L, nH, dH, _p(dqkv), _stream()),
+          "cxrk_attn_bwd")
+    return dqkv
+
+
+def embed_bwd(ids, dx, dword):
+    lib = _lib.load()
+    T, H = dx.shape
+    check(lib.cxrk_embed_bwd(_p(ids), _p(_chk(dx, "embed.dx")), T, H, _p(dword), _stream()), "cxrk_embed_bwd")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# heads
+# ----------------------------------------------------------------------------------------------------------------
+
+def l2norm_fwd(x: torch.Tensor, eps: float = 1e-12):
+    lib = _lib.load()
+    x = _chk(x, "l2norm.x").contiguous()
+    rows, D = x.shape
+    xhat = torch.empty_like(x)
+    norm = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib.cxrk_l2norm_fwd(_p(x), rows, D, float(eps), _p(xhat), _p(norm), _stream()), "cxrk_l2norm_fwd")
+    return xhat, norm
+
+
+def l2norm_bwd(dxhat, xhat, norm):
+    lib = _lib.load()
+    rows, D = xhat.shape
+    dx = torch.empty_like(xhat)
+    check(lib.cxrk_l2norm_bwd(_p(_chk(dxhat.contiguous(), "l2norm.dxhat")), _p(xhat), _p(norm), rows, D, _p(dx),
+                              _stream()), "cxrk_l2norm_bwd")
+    return dx
+
+
+def infonce_row_lse(S, diag_off, loss_out=None, loss_scale: float = 0.0, loss_accumulate: bool = False):
+    lib = _lib.load()
+    rows, cols = S.shape
+    lse = torch.empty(rows, dtype=torch.float32, device=S.device)
+    diag = torch.empty(rows, dtype=torch.float32, device=S.device)
+    check(lib.cxrk_infonce_row_lse(_p(_chk(S, "infonce.S")), S.stride(0), rows, cols, diag_off, _p(lse), _p(diag),
+                                   _p(loss_out), float(loss_scale), int(loss_accumulate), _stream()),
+          "cxrk_infonce_row_lse")
+    return lse, diag
+
+
+def infonce_grad_inplace(S, diag_off, lse_row, lse_col):
+    lib = _lib.load()
+    rows, cols = S.shape
+    check(lib.cxrk_infonce_grad_inplace(_p(S), S.stride(0), rows, cols, diag_off, _p(lse_row), _p(lse_col), _stream()),
+          "cxrk_infonce_grad_inplace")
+    return S
+
+
+def pairwise_cosine_fwd(x, y):
+    lib = _lib.load()
+    x = _chk(x, "cosine.x").contiguous()
+    y = _chk(y, "cosine.y").contiguous()
+    B, D = x.shape
+    Pn = y.shape[0]
+    if y.shape[1] != D:
+        raise ValueError(f"pairwise_cosine: x is [{B},{D}] but y is {tuple(y.shape)}")
+    cosv = torch.empty(B, Pn, dtype=torch.float32, device=x.device)
+    xn = torch.empty(B, dtype=torch.float32, device=x.device)
+    yn = torch.empty(Pn, dtype=torch.float32, device=x.device)
+    check(lib.cxrk_pairwise_cosine_fwd(_p(x), _p(y), B, Pn, D, _p(cosv), _p(xn), _p(yn), _stream()),
+          "cxrk_pairwise_cosine_fwd")
+    return cosv, xn, yn
+
+
+def pairwise_cosine_bwd(x, y, cosv, dcos, xn, yn, need_dx: bool = True):
+    lib = _lib.load()
+    B, D = x.shape
+    Pn = y.shape[0]
+    dx = torch.empty_like(x) if need_dx else None
+    dy = torch.empty_like(y)
+    wsb = lib.cxrk_pairwise_cosine_bwd_ws_bytes(B, Pn, D)
+    ws = workspace(wsb, x.device)
+    check(lib.cxrk_pairwise_cosine_bwd(_p(x), _p(y), _p(cosv), _p(_chk(dcos.contiguous(), "cosine.dcos")), _p(xn), _p(yn),
+                                       B, Pn, D, _p(dx), _p(dy), 0, _p(ws), ws.numel() * 4, _stream()),
+          "cxrk_pairwise_cosine_bwd")
+    return dx, dy
+
+
+def bce_posneg_fwd_bwd(cosv, labels, diff: bool = True, need_grad: bool = True):
+    """cos [B,2C] (2c = pos, 2c+1 = neg), labels [B,C] view (stride(1)==1) -> logits [B,C], dcos [B,2C], loss []"""
+    lib = _lib.load()
+    B, C2 = cosv.shape
+    C = C2 // 2
+    _chk(labels, "bce.labels")
+    if labels.dim() == 1:
+        labels = labels.unsqueeze(1)
+    if labels.shape[1] > 1 and labels.stride(1) != 1:
+        labels = labels.contiguous()
+    logits = torch.empty(B, C, dtype=torch.float32, device=cosv.device)
+    dcos = torch.empty_like(cosv) if need_grad else None
+    loss = torch.empty((), dtype=torch.float32, device=cosv.device)
+    ws = workspace(lib.cxrk_bce_posneg_ws_bytes(), cosv.device)
+    check(lib.cxrk_bce_posneg_fwd_bwd(_p(_chk(cosv, "bce.cos")), _p(labels), B, C, labels.stride(0), int(diff), _p(logits),
+                                      _p(dcos), _p(loss), _p(ws), ws.numel() * 4, _stream()), "cxrk_bce_posneg_fwd_bwd")
+    return logits, dcos, loss
+
+
+def eval_score(cosv, pred_diff: bool = False):
+    lib = _lib.load()
+    B, C2 = cosv.shape
+    C = C2 // 2
+    score = torch.empty(B, C, dtype=torch.float32, device=cosv.device)
+    pred = torch.empty(B, C, dtype=torch.float32, device=cosv.device)
+    check(lib.cxrk_eval_score(_p(_chk(cosv, "eval.cos")), B, C, int(pred_diff), _p(score), _p(pred), _stream()),
+          "cxrk_eval_score")
+    return score, pred
+
+
+def group_mean_fwd(x, G, n):
+    lib = _lib.load()
+    D = x.shape[-1]
+    out = torch.empty(G, D, dtype=torch.float32, device=x.device)
+    check(lib.cxrk_group_mean_fwd(_p(_chk(x.contiguous(), "group_mean.x")), G, n, D, _p(out), _stream()), "cxrk_group_mean_fwd")
+    return out
+
+
+def group_mean_bwd(dout, G, n):
+    lib = _lib.load()
+    D = dout.shape[-1]
+    din = torch.empty(G * n, D, dtype=torch.float32, device=dout.device)
+    check(lib.cxrk_group_mean_bwd(_p(_chk(dout.contiguous(), "group_mean.dout")), G, n, D, _p(din), _stream()),
+          "cxrk_group_mean_bwd")
+    return din
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# optimiser / continual learning
+# ----------------------------------------------------------------------------------------------------------------
+
+def adam_fused(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale: float = 1.0):
+    lib = _lib.load()
+    n = p.numel()
+    for nme, t in (("p", p), ("g", g), ("m", m), ("v", v)):
+        _chk(t, "adam." + nme)
+        if not t.is_contiguous() or t.numel() != n:
+            raise ValueError(f"adam.{nme}: must be contiguous with {n} elements")
+    check(lib.cxrk_adam_fused(_p(p), _p(g), _p(m), _p(v), n, float(lr), float(beta1), float(beta2), float(eps),
+                              float(weight_decay), int(step), float(grad_scale), _stream()), "cxrk_adam_fused")
+
+
+def sgd(p, g, lr, weight_decay: float = 0.0, grad_scale: float = 1.0):
+    lib = _lib.load()
+    check(lib.cxrk_sgd(_p(_chk(p, "sgd.p")), _p(_chk(g, "sgd.g")), p.numel(), float(lr), float(weight_decay),
+                       float(grad_scale), _stream()), "cxrk_sgd")
+
+
+def weight_reset(pnew, pold, threshold, counters):
+    """In place: restore entries of pnew whose |pnew-pold| < min + thr*(max-min); counters[0] += #restored (uint64)."""
+    lib = _lib.load()
+    ws = workspace(lib.cxrk_weight_reset_ws_bytes(), pnew.device)
+    check(lib.cxrk_weight_reset(_p(_chk(pnew, "reset.new")), _p(_chk(pold, "reset.old")), pnew.numel(), float(threshold),
+                                _p(counters), _p(ws), ws.numel() * 4, _stream()), "cxrk_weight_reset")

@@ -1,0 +1,284 @@
+"""Kernel-level parity: every cxrk entry point against plain PyTorch-CPU fp32 on the same seeded inputs.
+Tolerance: the north star's 1e-3 relative fp32 bar; the kernels are fp32 end to end so they are checked much
+tighter (2e-5 of the output scale) to catch layout / indexing mistakes."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from incremental_multimodal_medical_learning_ii_amd import kernels as K  # noqa: E402
+from oracle import ref_loss, ref_step  # noqa: E402
+
+DEV = "cuda"
+
+
+def close(a, b, tol=2e-5, what=""):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = b.abs().max().clamp_min(1e-20)
+    err = (a - b).abs().max() / scale
+    assert torch.isfinite(a).all(), what
+    assert err < tol, f"{what}: rel-to-max err {err:.3e} (tol {tol})"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + 1000 * len(shape) + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,Kd", [(200, 136, 72), (128, 128, 32), (50, 300, 40), (300, 48, 132), (1024, 128, 768), (33, 64, 8)])
+def test_gemm_nt_epilogues(M, N, Kd):
+    x, w, b, r = rnd(M, Kd), rnd(N, Kd, seed=1), rnd(N, seed=2), rnd(M, N, seed=3)
+    xd, wd, bd, rd = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
+    close(K.linear_fwd(xd, wd), x @ w.T, what="plain")
+    close(K.linear_fwd(xd, wd, bias=bd, act=K.ACT_RELU, residual=rd), F.relu(x @ w.T + b + r), what="bias+res+relu")
+    pre = torch.empty(M, N, device=DEV)
+    close(K.linear_fwd(xd, wd, bias=bd, act=K.ACT_GELU, preact_out=pre), F.gelu(x @ w.T + b), what="gelu")
+    close(pre, x @ w.T + b, what="preact")
+
+
+@pytest.mark.parametrize("M,N,Kd", [(200, 136, 72), (64, 256, 128), (512, 64, 260), (1000, 768, 128)])
+def test_gemm_nn_tn(M, N, Kd):
+    dy, w, x, aux = rnd(M, N), rnd(N, Kd, seed=1), rnd(M, Kd, seed=2), rnd(M, Kd, seed=3)
+    dyd, wd, xd, auxd = dy.to(DEV), w.to(DEV), x.to(DEV), aux.to(DEV)
+    close(K.linear_bwd_data(dyd, wd), dy @ w, what="dgrad")
+    close(K.linear_bwd_data(dyd, wd, aux=auxd, auxmode=K.AUX_RELU_MASK), (dy @ w) * (aux > 0), what="dgrad relu mask")
+    a = aux.clone().requires_grad_(True)
+    F.gelu(a).backward(dy @ w)
+    close(K.linear_bwd_data(dyd, wd, aux=auxd, auxmode=K.AUX_GELU_GRAD), a.grad, what="dgrad gelu'")
+    dw = torch.zeros(N, Kd, device=DEV)
+    close(K.linear_bwd_weight(dyd, xd, dw), dy.T @ x, what="wgrad")
+    close(K.linear_bwd_weight(dyd, xd, dw, accumulate=True), 2 * (dy.T @ x), what="wgrad accumulate")
+    out = torch.empty(N, Kd, device=DEV)
+    close(K.gemm(dyd, xd, out, N, Kd, M, True, False, splitk=3), dy.T @ x, what="wgrad splitk=3")
+    cs = torch.empty(N, device=DEV)
+    close(K.colsum(dyd, cs), dy.sum(0), what="colsum")
+
+
+def test_gemm_strided_rows_and_large_splitk():
+    # CLS-row gather: A rows with stride L*H (modelling_cxrbert.py:98-99)
+    h = rnd(16 * 32, 768)
+    w = rnd(128, 768, seed=1)
+    hd = h.to(DEV)
+    cls = hd.view(16, 32 * 768)[:, :768]
+    close(K.linear_fwd(cls, w.to(DEV)), h.view(16, 32, 768)[:, 0] @ w.T, what="strided A")
+    dy, x = rnd(8192, 256), rnd(8192, 128, seed=4)
+    dw = torch.empty(256, 128, device=DEV)
+    close(K.linear_bwd_weight(dy.to(DEV), x.to(DEV), dw), dy.T @ x, tol=5e-5, what="wgrad auto split-K")
+
+
+def test_gemm_rejects_cpu_and_bad_alignment():
+    with pytest.raises(ValueError):
+        K.linear_fwd(torch.zeros(4, 8), torch.zeros(4, 8))
+    with pytest.raises(ValueError):
+        K.linear_fwd(torch.zeros(4, 6, device=DEV), torch.zeros(4, 6, device=DEV))  # K % 4 != 0
+
+
+# ------------------------------------------------------------------------------------------------ conv
+CONVS = [  # N,H,W,C,Ko,R,stride,pad
+    (2, 14, 14, 64, 64, 1, 1, 0), (2, 14, 14, 64, 256, 1, 1, 0), (3, 9, 9, 128, 128, 3, 1, 1),
+    (2, 14, 14, 128, 128, 3, 2, 1), (2, 14, 14, 256, 512, 1, 2, 0), (2, 12, 12, 64, 64, 3, 1, 1),
+    (2, 15, 15, 64, 128, 3, 2, 1),
+]
+
+
+def _conv_case(N, H, W, C, Ko, R, stride, pad, seed=0, cin_real=None):
+    cr = cin_real or C
+    x = rnd(N, cr, H, W, seed=seed)
+    w = rnd(Ko, cr, R, R, seed=seed + 1, scale=1.0 / math.sqrt(cr * R * R))
+    gamma, beta = 1 + 0.1 * rnd(Ko, seed=seed + 2), 0.1 * rnd(Ko, seed=seed + 3)
+    rm, rv = 0.1 * rnd(Ko, seed=seed + 4), 0.5 + rnd(Ko, seed=seed + 5).abs()
+    return x, w, gamma, beta, rm, rv
+
+
+@pytest.mark.parametrize("cfg", CONVS + [(2, 32, 32, 4, 64, 7, 2, 3)])
+def test_conv_bn_relu_fwd_bwd(cfg):
+    N, H, W, C, Ko, R, stride, pad = cfg
+    cr = 3 if C == 4 else C
+    x, w, gamma, beta, rm, rv = _conv_case(*cfg, cin_real=cr)
+    for t in (x, w, gamma, beta):
+        t.requires_grad_(True)
+    z = F.conv2d(x, w, stride=stride, padding=pad)
+    ybn = F.batch_norm(z, rm, rv, gamma, beta, training=False, eps=1e-5)
+    res = rnd(*ybn.shape, seed=9)
+    y = F.relu(ybn + res)
+    gy = rnd(*y.shape, seed=10)
+    y.backward(gy)
+    Ho, Wo = y.shape[2], y.shape[3]
+    # device side
+    xd = K.nchw_to_nhwc(x.detach().to(DEV), C)
+    w_cl = w.detach().permute(0, 2, 3, 1).contiguous().to(DEV)  # [Ko][R][S][C_real]
+    ws = torch.empty(Ko, R, R, C, device=DEV)
+    sc, sh, rstd = (torch.empty(Ko, device=DEV) for _ in range(3))
+    g_, b_, rm_, rv_ = gamma.detach().to(DEV), beta.detach().to(DEV), rm.to(DEV), rv.to(DEV)
+    K.bn_fold(w_cl, g_, b_, rm_, rv_, 1e-5, Ko, R * R, cr, C, ws, sc, sh, rstd)
+    resd = res.permute(0, 2, 3, 1).contiguous().to(DEV)
+    yd = torch.empty(N, Ho, Wo, Ko, device=DEV)
+    K.conv_fwd(xd, ws, sh, resd, yd, N, H, W, C, Ko, R, R, stride, pad, True)
+    close(K.nhwc_to_nchw(yd), y, what="conv fwd")
+    # backward: mask by own relu (host-side here; fused into the producing dgrad in the model)
+    gyd = gy.permute(0, 2, 3, 1).contiguous().to(DEV) * (yd > 0)
+    sumdy = torch.empty(Ko, device=DEV)
+    K.colsum(gyd.view(-1, Ko), sumdy)
+    dw = torch.empty(Ko, R, R, cr, device=DEV)
+    dg, db = torch.empty(Ko, device=DEV), torch.empty(Ko, device=DEV)
+    K.conv_bwd_params(xd, gyd, w_cl, sc, rstd, rm_, sumdy, dw, dg, db, False, N, H, W, cr, C, Ko, R, R, stride, pad)
+    close(dw.permute(0, 3, 1, 2), w.grad, tol=5e-5, what="conv wgrad")
+    close(dg, gamma.grad, tol=5e-5, what="bn dgamma")
+    close(db, beta.grad, tol=5e-5, what="bn dbeta")
+    if C != 4:
+        dxd = torch.empty(N, H, W, C, device=DEV)
+        K.conv_bwd_data(gyd, ws, None, None, dxd, N, H, W, C, Ko, R, R, stride, pad)
+        close(K.nhwc_to_nchw(dxd), x.grad, tol=5e-5, what="conv dgrad")
+        add = rnd(N, H, W, C, seed=11).to(DEV)
+        K.conv_bwd_data(gyd, ws, add, xd, dxd, N, H, W, C, Ko, R, R, stride, pad)
+        close(K.nhwc_to_nchw(dxd), (x.grad + K.nhwc_to_nchw(add).cpu()) * (x.detach() > 0), tol=5e-5, what="dgrad+res+mask")
+
+
+def test_maxpool_spatial_mean():
+    x = F.relu(rnd(2, 8, 13, 13)).requires_grad_(True)
+    y = F.max_pool2d(x, 3, 2, 1)
+    gy = rnd(*y.shape, seed=3)
+    y.backward(gy)
+    xd = K.nchw_to_nhwc(x.detach().to(DEV), 8)
+    yd, idx = K.maxpool_fwd(xd)
+    close(K.nhwc_to_nchw(yd), y, what="maxpool fwd")
+    dx = K.maxpool_bwd(gy.permute(0, 2, 3, 1).contiguous().to(DEV), idx, xd, False)
+    close(K.nhwc_to_nchw(dx), x.grad, what="maxpool bwd")
+    p = rnd(3, 49, 128)
+    close(K.spatial_mean_fwd(p.to(DEV)), p.mean(1), what="spatial mean")
+    g = rnd(3, 128, seed=1)
+    close(K.spatial_mean_bwd(g.to(DEV), 49), (g / 49)[:, None, :].expand(3, 49, 128), what="spatial mean bwd")
+
+
+# ------------------------------------------------------------------------------------------------ BERT pieces
+@pytest.mark.parametrize("H", [768, 128, 64])
+def test_layernorm_fwd_bwd(H):
+    rows = 77
+    x, r = rnd(rows, H), rnd(rows, H, seed=1)
+    g, b = (1 + 0.1 * rnd(H, seed=2)).requires_grad_(True), (0.1 * rnd(H, seed=3)).requires_grad_(True)
+    s = (x + r).requires_grad_(True)
+    y = F.layer_norm(s, (H,), g, b, 1e-12)
+    gy = rnd(rows, H, seed=4)
+    y.backward(gy)
+    yd, xhat, rstd = K.residual_ln_fwd(x.to(DEV), r.to(DEV), g.detach().to(DEV), b.detach().to(DEV), 1e-12)
+    close(yd, y, what="ln fwd")
+    dg, db = torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+    add = rnd(rows, H, seed=5)
+    dx = K.residual_ln_bwd(gy.to(DEV), xhat, rstd, g.detach().to(DEV), dg, db, dx_add=add.to(DEV))
+    close(dx, s.grad + add, what="ln dx")
+    close(dg, g.grad, what="ln dgamma")
+    close(db, b.grad, what="ln dbeta")
+
+
+def test_embed_ln_and_scatter():
+    V, H, L, B = 50, 64, 8, 3
+    word, pos, typ = rnd(V, H), rnd(16, H, seed=1), rnd(2, H, seed=2)
+    g, b = 1 + 0.1 * rnd(H, seed=3), 0.1 * rnd(H, seed=4)
+    ids = torch.randint(0, V, (B, L), generator=torch.Generator().manual_seed(5))
+    ref = F.layer_norm(word[ids] + pos[:L][None] + typ[0], (H,), g, b, 1e-12)
+    y, xhat, rstd = K.embed_ln_fwd(ids.to(DEV), word.to(DEV), pos.to(DEV), typ[0].contiguous().to(DEV), g.to(DEV), b.to(DEV), 1e-12, L)
+    close(y.view(B, L, H), ref, what="embed ln")
+    dx = rnd(B * L, H, seed=6)
+    dword = torch.zeros(V, H, device=DEV)
+    K.embed_bwd(ids.to(DEV).view(-1), dx.to(DEV), dword)
+    refw = torch.zeros(V, H).index_add_(0, ids.view(-1), dx)
+    close(dword, refw, what="embed scatter-add")
+
+
+@pytest.mark.parametrize("L,ragged", [(32, False), (32, True), (17, True), (64, False)])
+def test_attention_fwd_bwd(L, ragged):
+    B, nH, dH = 3, 4, 64
+    qkv = rnd(B * L, 3 * nH * dH, scale=0.7).requires_grad_(True)
+    mask = torch.ones(B, L, dtype=torch.int64)
+    if ragged:
+        for i in range(B):
+            mask[i, max(1, L - 3 * i - 2):] = 0
+    q, k, v = qkv.view(B, L, 3, nH, dH).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) / math.sqrt(dH) + (1.0 - mask[:, None, None, :].float()) * torch.finfo(torch.float32).min
+    ctx = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * L, nH * dH)
+    gc = rnd(B * L, nH * dH, seed=2)
+    ctx.backward(gc)
+    qd = qkv.detach().to(DEV)
+    cd, probs = K.attn_fwd(qd, mask.to(DEV), B, L, nH, dH)
+    close(cd, ctx, what="attn fwd")
+    dq = K.attn_bwd(qd, probs, gc.to(DEV), B, L, nH, dH)
+    close(dq, qkv.grad, tol=5e-5, what="attn bwd")
+
+
+# ------------------------------------------------------------------------------------------------ heads
+def test_l2norm_infonce_pieces(golden_dir):
+    import numpy as np
+    g = np.load(f"{golden_dir}/g4_infonce.npz")
+    I, T = torch.from_numpy(g["I"]), torch.from_numpy(g["T"])
+    ih, inorm = K.l2norm_fwd(I.to(DEV))
+    close(ih, F.normalize(I, dim=1), what="l2norm")
+    d = rnd(32, 128, seed=3)
+    x = I.clone().requires_grad_(True)
+    F.normalize(x, dim=1).backward(d)
+    close(K.l2norm_bwd(d.to(DEV), ih, inorm), x.grad, what="l2norm bwd")
+    S = torch.from_numpy(g["S_tau0.07"])
+    lse, diag = K.infonce_row_lse(S.to(DEV), 0)
+    close(lse, torch.logsumexp(S, 1), what="row lse")
+    close(diag, S.diag(), what="diag")
+
+
+def test_pairwise_cosine_bce_eval(golden_dir):
+    B, D, C = 70, 128, 5
+    x, y = rnd(B, D).requires_grad_(True), rnd(2 * C, D, seed=1).requires_grad_(True)
+    labels = (rnd(B, C, seed=2) > 0.5).float()
+    cos = ref_loss.pairwise_cosine_similarity(x, y)
+    logits = cos[:, 0::2] - cos[:, 1::2]
+    loss = F.binary_cross_entropy_with_logits(logits, labels)
+    loss.backward()
+    cd, xn, yn = K.pairwise_cosine_fwd(x.detach().to(DEV), y.detach().to(DEV))
+    close(cd, cos, what="cosine fwd")
+    lg, dcos, ls = K.bce_posneg_fwd_bwd(cd, labels.to(DEV))
+    close(lg, logits, what="logits")
+    assert abs(ls.item() - loss.item()) < 1e-6
+    dx, dy = K.pairwise_cosine_bwd(x.detach().to(DEV), y.detach().to(DEV), cd, dcos, xn, yn)
+    close(dx, x.grad, what="cosine dx")
+    close(dy, y.grad, what="cosine dy")
+    # class-incremental column subset (Trainer.py:701-714): labels[:, :3] is a strided view
+    lg3, _, ls3 = K.bce_posneg_fwd_bwd(cd[:, :6].contiguous(), labels.to(DEV)[:, :3])
+    assert abs(ls3.item() - F.binary_cross_entropy_with_logits(logits[:, :3], labels[:, :3]).item()) < 1e-6
+    sc, pr = K.eval_score(cd)
+    close(sc, (cos[:, 0::2] + 1) / 2, what="score")
+    assert torch.equal(pr.cpu(), (cos[:, 0::2] > cos[:, 1::2]).float())
+    e = rnd(10 * 4, D, seed=5)
+    close(K.group_mean_fwd(e.to(DEV), 10, 4), e.view(10, 4, D).mean(1), what="group mean")
+    gm = rnd(10, D, seed=6)
+    close(K.group_mean_bwd(gm.to(DEV), 10, 4), (gm / 4)[:, None].expand(10, 4, D).reshape(40, D), what="group mean bwd")
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def test_adam_sgd_weight_reset():
+    n = 65920 + 3
+    p0, gs = rnd(n), [rnd(n, seed=s) for s in range(1, 4)]
+    p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=1e-3)
+    pd, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step, g in enumerate(gs, 1):
+        p.grad = g.clone()
+        opt.step()
+        K.adam_fused(pd, g.to(DEV), m, v, 1e-3, 0.9, 0.999, 1e-8, 0.0, step)
+        close(pd, p, tol=1e-6, what=f"adam step {step}")
+    q = p0.clone().requires_grad_(True)
+    so = torch.optim.SGD([q], lr=0.1)
+    q.grad = gs[0].clone()
+    so.step()
+    qd = p0.to(DEV)
+    K.sgd(qd, gs[0].to(DEV), 0.1)
+    close(qd, q, tol=1e-6, what="sgd")
+    new, old = rnd(5000, seed=7), rnd(5000, seed=8)
+    ref, cnt = ref_step.weight_reset(new, old, 0.3)
+    nd = new.to(DEV)
+    counters = torch.zeros(2, dtype=torch.int64, device=DEV)
+    K.weight_reset(nd, old.to(DEV), 0.3, counters)
+    assert torch.equal(nd.cpu(), ref)
+    assert counters[0].item() == cnt
