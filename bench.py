@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: joint image+text contrastive TRAIN step, images/sec (BASELINE.json `metric`).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = ResNet-50 image encoder (224x224) + 12-layer CXR-BERT (32 tokens) forward, L2-normalise, all-gather,
+InfoNCE over the global batch, hand-written backward through both encoders, gradient all-reduce, fused Adam on all
+~133 M parameters.  Per-GPU batch is 1024 (global batch 1024 at N=1 = the configuration the metric is quoted on;
+weak scaling for N>1: 8192 global at N=8 = BASELINE config 5).  fp32 end to end (exact-fp32 MFMA), synthetic
+data resident in HBM before the timed region, seeded random-init weights.
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+FLOP_PER_PAIR_STEP = 41.1e9     # 3 x (8.2 GFLOP ResNet-50+projector + 5.5 GFLOP CXR-BERT, L=32, no MLM head); SURVEY.md §8d
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch-per-gpu", type=int, default=1024)
+    ap.add_argument("--seq-len", type=int, default=32)
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--temperature", type=float, default=0.07)
+    ap.add_argument("--cpu-baseline-batch", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch: int, seq_len: int, image_size: int, tau: float):
+    """The CPU oracle (PyTorch fp32, all host cores) timed on a bounded sample of the same workload: full-size models,
+    a global batch of `batch` pairs, 1 warm-up + 2 timed steps."""
+    from incremental_multimodal_medical_learning_ii_amd import synthetic as syn
+    from oracle import ref_image, ref_step, ref_text
+    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(ncores)
+    prm, buf = ref_image.image_param_shapes()
+    g = torch.Generator().manual_seed(27)
+    ip = {k: (torch.randn(s, generator=g) * (0.05 if len(s) > 1 else 0.0) + (1.0 if len(s) == 1 else 0.0)) for k, s in prm.items()}
+    for k, s in buf.items():
+        ip[k] = torch.zeros(s, dtype=torch.int64) if k.endswith("num_batches_tracked") else (torch.ones(s) if k.endswith("var") else torch.zeros(s))
+    tp = {k: torch.randn(s, generator=g) * 0.02 + (1.0 if k.endswith("LayerNorm.weight") else 0.0)
+          for k, s in ref_text.cxrbert_param_shapes().items()}
+    leaves = [v.requires_grad_(True) for k, v in list(ip.items()) + list(tp.items()) if v.is_floating_point() and "running" not in k]
+    opt = torch.optim.Adam(leaves, lr=1e-4)
+    images = syn.synthetic_images(batch, image_size)
+    ids, mask = syn.synthetic_tokens(batch, seq_len)
+    ref_step.joint_step(ip, tp, images, ids, mask, tau, opt)
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        ref_step.joint_step(ip, tp, images, ids, mask, tau, opt)
+    dt = (time.perf_counter() - t0) / n
+    return {"value": batch / dt, "unit": "images/sec", "cores": ncores, "kind": "port",
+            "sample": f"oracle joint step (ResNet-50 {image_size}px + 12-layer CXR-BERT L={seq_len} + InfoNCE + Adam), global batch "
+                      f"{batch}, 1 warm-up + {n} timed steps, {dt:.2f} s/step; per-pair cost is batch-independent apart from "
+                      f"the negligible B^2 logits"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: using {world} rank(s)", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from incremental_multimodal_medical_learning_ii_amd import kernels as K
+    from incremental_multimodal_medical_learning_ii_amd import synthetic as syn
+    from incremental_multimodal_medical_learning_ii_amd.contrastive import JointContrastiveTrainer
+    from incremental_multimodal_medical_learning_ii_amd.health_multimodal.image.model import get_biovil_resnet
+    from incremental_multimodal_medical_learning_ii_amd.health_multimodal.text import CXRBertConfig, CXRBertModel
+
+    torch.manual_seed(27)                       # identical replicas on every rank
+    im = get_biovil_resnet(None).eval()         # BN on running statistics (the reference's only mode)
+    tm = CXRBertModel(CXRBertConfig()).eval()   # dropout inactive
+    trainer = JointContrastiveTrainer(im.to(dev), tm.to(dev), lr=1e-4, temperature=args.temperature)
+    B = args.batch_per_gpu
+    images = syn.synthetic_images(B, args.image_size, seed=27 + rank).to(dev)
+    ids, mask = syn.synthetic_tokens(B, args.seq_len, seed=28 + rank)
+    ids, mask = ids.to(dev), mask.to(dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = trainer.step(images, ids, mask)
+    sync()
+    prof = (not args.no_roofline) and rank == 0
+    if prof:
+        K.profiler.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(images, ids, mask)
+    sync()
+    dt = time.perf_counter() - t0
+    K.profiler.stop()
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    final_loss = float(loss.item()) if loss is not None else float("nan")
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        out = {
+            "metric": "contrastive train-step images/sec at global batch 1024; 1/2/4/8-GPU scaling",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32",
+            "data": "synthetic",
+            "config": {"workload": "joint image+text contrastive train step: ResNet-50 (224x224) + CXR-BERT (12 layers, 32 tokens) "
+                                   "-> InfoNCE over the global batch -> backward through both encoders -> fused Adam "
+                                   "(BASELINE config 3 at N=1: batch 1024 on one MI355X; config 5 at N=8: global 8192)",
+                       "global_batch": world * B, "batch_per_gpu": B, "seq_len": args.seq_len, "image_size": args.image_size,
+                       "temperature": args.temperature, "parallelism": f"dp{world}", "weights": "seeded random init",
+                       "batchnorm": "running statistics (eval mode), gamma/beta trained"},
+            "final_loss": final_loss,
+            "model_tflops_per_s": FLOP_PER_PAIR_STEP * world * B * args.steps / dt / 1e12,
+        }
+        if prof:
+            summ = K.profiler.summary()
+            if summ:
+                key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+                achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                tot_ms = sum(v["ms"] for v in summ.values())
+                tot_fl = sum(v["flops"] for v in summ.values())
+                out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "kernel": key,
+                                   "launches_per_step": d["launches"] / args.steps,
+                                   "avg_launch_ms": d["ms"] / d["launches"],
+                                   "gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+                                   "family": {"kernel": "gemm_f32_kernel<*> (all instantiations)",
+                                              "achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
+                                              "share_of_step_time": tot_ms / (dt * 1e3)}}
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch, args.seq_len, args.image_size, args.temperature)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

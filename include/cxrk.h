@@ -56,7 +56,9 @@ int cxrk_colsum(const float* X, long ldx, long rows, int cols, float* out, float
  *               scale = gamma*rstd, shift = beta - mean*scale, rstd = rsqrt(var+eps).
  * fwd:        y = relu?( conv(x, w_scaled) + shift + residual? )
  * bwd_data:   dx = (relu_src>0)? * ( conv^T(dy, w_scaled) + residual? )        (dy already masked by its own ReLU)
- * bwd_params: dW = scale * wgrad(x, dy);  dgamma = rstd*(<w,wgrad> - mean*sumdy);  dbeta = sumdy
+ * bn_bwd_reduce: sumdy[c] = sum dy,  sumdyy[c] = sum dy * (y - sub - beta[c])   (y - sub = the BN output where dy != 0)
+ * bwd_params: dW = scale * wgrad(x, dy);  dbeta = sumdy;  dgamma = sumdyy / gamma
+ *             (when gamma/sumdyy are NULL or gamma == 0: rstd*(<w,wgrad> - mean*sumdy))
  */
 int cxrk_bn_fold(const float* w, const float* gamma, const float* beta, const float* rmean, const float* rvar,
                  float eps, int Ko, int taps, int C, int Cpad, float* w_scaled, float* scale, float* shift,
@@ -68,8 +70,12 @@ int cxrk_conv_bn_act_bwd_data(const float* dy, const float* w_scaled, const floa
                               float* dx, int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad,
                               hipStream_t stream);
 size_t cxrk_conv_wgrad_ws_bytes(int N, int H, int W, int Cpad, int Ko, int R, int S, int stride, int pad);
+size_t cxrk_bn_bwd_reduce_ws_bytes(long rows, int C);
+int cxrk_bn_bwd_reduce(const float* dy, const float* y, const float* sub, const float* beta, long rows, int C,
+                       float* sumdy, float* sumdyy, float* ws, size_t ws_bytes, hipStream_t stream);
 int cxrk_conv_bn_act_bwd_params(const float* x, const float* dy, const float* w, const float* scale, const float* rstd,
-                                const float* rmean, const float* sumdy, float* dw, float* dgamma, float* dbeta,
+                                const float* rmean, const float* sumdy, const float* gamma, const float* sumdyy,
+                                float* dw, float* dgamma, float* dbeta,
                                 int accumulate, int N, int H, int W, int C, int Cpad, int Ko, int R, int S, int stride,
                                 int pad, float* ws, size_t ws_bytes, hipStream_t stream);
 
@@ -92,7 +98,7 @@ int cxrk_spatial_mean_bwd(const float* dy, float* dx, int N, int P, int C, hipSt
  * residual_ln: y = LayerNorm(x + res)                                             (BertSelfOutput / BertOutput)
  *              xhat, rstd saved for bwd; bwd: dx = LN'(dy) + dx_add, dgamma/dbeta reduced deterministically.
  * attn:        ctx = softmax(Q K^T / sqrt(d) + keymask) V per (sequence, head); qkv is the fused [T][3*nH*d]
- *              projection output; probs [B][nH][L][L] saved for bwd.  L <= 64, d == 64.
+ *              projection output; probs [B][nH][L][L] saved for bwd.  L <= 64, d <= 64 (multiple of 4).
  * embed_bwd:   dword[ids[t]] += dx[t]   (fp32 atomics)
  */
 int cxrk_embed_ln_fwd(const long* ids, const float* word, const float* pos, const float* type, const float* gamma,
@@ -109,6 +115,8 @@ int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, int nH, int 
 int cxrk_attn_bwd(const float* qkv, const float* probs, const float* dctx, int B, int L, int nH, int dH, float* dqkv,
                   hipStream_t stream);
 int cxrk_embed_bwd(const long* ids, const float* dx, long T, int H, float* dword, hipStream_t stream);
+/* dx = dy * gelu'(pre): the erf-GELU between dense_to_hidden and LayerNorm of BertProjectionHead (modelling_cxrbert.py:45-46). */
+int cxrk_gelu_bwd(const float* dy, const float* pre, long n, float* dx, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Similarity / loss heads.
@@ -141,6 +149,10 @@ int cxrk_bce_posneg_fwd_bwd(const float* cosv, const float* labels, long B, int 
 int cxrk_eval_score(const float* cosv, long B, int C, int pred_diff, float* score, float* pred, hipStream_t stream);
 int cxrk_group_mean_fwd(const float* in, int G, int n, int D, float* out, hipStream_t stream);
 int cxrk_group_mean_bwd(const float* dout, int G, int n, int D, float* din, hipStream_t stream);
+/* out = alpha * (alpha_dev ? *alpha_dev : 1) * x * (mask_src > 0): nn.ReLU backward (models.py:10) and chain-rule scaling
+ * by an upstream scalar gradient that lives on the device. */
+int cxrk_scale_mask(const float* x, const float* mask_src, const float* alpha_dev, float alpha, long n, float* out,
+                    hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Optimiser / continual learning.

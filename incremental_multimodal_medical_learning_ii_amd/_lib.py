@@ -25,7 +25,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_conv_bn_act_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "cxrk_conv_bn_act_bwd_data": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "cxrk_conv_wgrad_ws_bytes": (Z, [I, I, I, I, I, I, I, I, I]),
-    "cxrk_conv_bn_act_bwd_params": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, Z, P]),
+    "cxrk_bn_bwd_reduce_ws_bytes": (Z, [L, I]),
+    "cxrk_bn_bwd_reduce": (I, [P, P, P, P, L, I, P, P, P, Z, P]),
+    "cxrk_conv_bn_act_bwd_params": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, Z, P]),
     "cxrk_nchw_to_nhwc": (I, [P, P, I, I, I, I, I, P]),
     "cxrk_nhwc_to_nchw": (I, [P, P, I, I, I, I, P]),
     "cxrk_maxpool_fwd": (I, [P, P, P, I, I, I, I, P]),
@@ -39,6 +41,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_attn_fwd": (I, [P, P, I, I, I, I, P, P, P]),
     "cxrk_attn_bwd": (I, [P, P, P, I, I, I, I, P, P]),
     "cxrk_embed_bwd": (I, [P, P, L, I, P, P]),
+    "cxrk_gelu_bwd": (I, [P, P, L, P, P]),
     "cxrk_l2norm_fwd": (I, [P, L, I, F, P, P, P]),
     "cxrk_l2norm_bwd": (I, [P, P, P, L, I, P, P]),
     "cxrk_infonce_row_lse": (I, [P, L, I, I, I, P, P, P, F, I, P]),
@@ -51,6 +54,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_eval_score": (I, [P, L, I, I, P, P, P]),
     "cxrk_group_mean_fwd": (I, [P, I, I, I, P, P]),
     "cxrk_group_mean_bwd": (I, [P, I, I, I, P, P]),
+    "cxrk_scale_mask": (I, [P, P, P, F, L, P, P]),
     "cxrk_adam_fused": (I, [P, P, P, P, L, F, F, F, F, F, I, F, P]),
     "cxrk_sgd": (I, [P, P, L, F, F, F, P]),
     "cxrk_weight_reset_ws_bytes": (Z, []),

@@ -1,0 +1,57 @@
+"""The north-star step: joint image + text embedding and symmetric InfoNCE, data-parallel over the GPUs of a node.
+
+    images [B,3,224,224] --ImageModel--> I [B,128] \
+                                                     > L2-normalise, all-gather, S = I_hat T_hat^T / tau, InfoNCE
+    token ids [B,32]     --CXRBertModel-> T [B,128] /
+    loss.backward() -> encoder backward (hand-written HIP) -> flat-gradient all-reduce (RCCL) -> fused Adam
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  Weights are replicated; the global
+batch is sharded by rows.  Communication per step: all-gather of [B,256] normalised embeddings, all-gather of [B,2]
+log-sum-exps, a scalar all-reduce for the reported loss, and the bucketed all-reduce of the ~133 M-parameter flat
+gradient buffer.  This step is NOT in the reference: temperature is an explicit
+argument (default 0.07, the usual CLIP-style value; the reference specifies none).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import functional as Fh
+from . import optim as cxr_optim
+
+
+class JointContrastiveTrainer:
+    def __init__(self, image_model: torch.nn.Module, text_model: torch.nn.Module, lr: float = 1e-4,
+                 temperature: float = 0.07, group=None, train_mlm_head: bool = False):
+        self.image_model, self.text_model = image_model, text_model
+        self.temperature, self.group = temperature, group
+        image_model.prepare_()
+        text_model.prepare_()
+        params = [p for n, p in image_model.named_parameters() if not n.startswith("encoder.encoder.fc.")]
+        tparams = []
+        for n, p in text_model.named_parameters():
+            if n.startswith("cls.predictions.") and not train_mlm_head:
+                continue  # MLM head: no gradient on this path
+            tparams.append(p)
+        self.optimizer = cxr_optim.Adam(params + tparams, lr=lr)
+        text_model.prepare_()
+        self.world = 1
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            self.world = dist.get_world_size(group)
+
+    def forward_loss(self, images: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        img = self.image_model(images)
+        txt = self.text_model.get_projected_text_embeddings(input_ids, attention_mask, normalize_embeddings=False)
+        return Fh.infonce_loss(img, txt, self.temperature, self.group)
+
+    def step(self, images: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        """One optimisation step on this rank's shard; returns the global-batch loss (device scalar, no host sync)."""
+        self.optimizer.zero_grad()
+        loss = self.forward_loss(images, input_ids, attention_mask)
+        loss.backward()
+        if self.world > 1:
+            self.optimizer.all_reduce_grads(self.group)
+        self.optimizer.step()
+        return loss.detach()

@@ -120,23 +120,24 @@ __global__ void ln_bwd_final_kernel(const float* __restrict__ part, int nblk, in
 // Q,K,V live in one fused [T][3*nH*64] buffer (the QKV GEMM output).  Everything is staged in LDS; the products are
 // small (2*L*L*64 FLOP each) and run on the fp32 VALU.  probs [B][nH][L][L] are saved for the backward.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int AD = 64;       // head dim
+constexpr int AD = 64;       // max head dim
 constexpr int AL = 64;       // max sequence length handled here
-constexpr int ALD = AD + 1;  // LDS row pad
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const long* __restrict__ mask, int L,
-                                                       int nH, float scale, float* __restrict__ ctx,
+                                                       int nH, int dH, float scale, float* __restrict__ ctx,
                                                        float* __restrict__ probs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ALD = dH + 1;
   float* Qs = smem; float* Ks = Qs + L * ALD; float* Vs = Ks + L * ALD; float* Ps = Vs + L * ALD;  // Ps[L][L+1]
   const int b = blockIdx.x / nH, hd = blockIdx.x % nH;
-  const int ld = 3 * nH * AD;
-  const float* base = qkv + (long)b * L * ld + hd * AD;
-  for (int i = threadIdx.x; i < L * (AD / 4); i += 256) {
-    const int row = i / (AD / 4), c4 = i % (AD / 4);
+  const int ld = 3 * nH * dH;
+  const int d4 = dH / 4;
+  const float* base = qkv + (long)b * L * ld + hd * dH;
+  for (int i = threadIdx.x; i < L * d4; i += 256) {
+    const int row = i / d4, c4 = i % d4;
     const float4 q = *reinterpret_cast<const float4*>(base + (long)row * ld + c4 * 4);
-    const float4 k = *reinterpret_cast<const float4*>(base + (long)row * ld + nH * AD + c4 * 4);
-    const float4 v = *reinterpret_cast<const float4*>(base + (long)row * ld + 2 * nH * AD + c4 * 4);
+    const float4 k = *reinterpret_cast<const float4*>(base + (long)row * ld + nH * dH + c4 * 4);
+    const float4 v = *reinterpret_cast<const float4*>(base + (long)row * ld + 2 * nH * dH + c4 * 4);
     float* qd = Qs + row * ALD + c4 * 4; qd[0] = q.x; qd[1] = q.y; qd[2] = q.z; qd[3] = q.w;
     float* kd = Ks + row * ALD + c4 * 4; kd[0] = k.x; kd[1] = k.y; kd[2] = k.z; kd[3] = k.w;
     float* vd = Vs + row * ALD + c4 * 4; vd[0] = v.x; vd[1] = v.y; vd[2] = v.z; vd[3] = v.w;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     const int i = e / L, j = e % L;
     float s = 0.f;
 #pragma unroll 16
-    for (int d = 0; d < AD; ++d) s = fmaf(Qs[i * ALD + d], Ks[j * ALD + d], s);
+    for (int d = 0; d < dH; ++d) s = fmaf(Qs[i * ALD + d], Ks[j * ALD + d], s);
     s *= scale;
     if (mask && mask[(long)b * L + j] == 0) s = -INFINITY;
     Ps[i * LP + j] = s;
@@ -172,32 +173,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  float* out = ctx + (long)b * L * (nH * AD) + hd * AD;
-  for (int e = threadIdx.x; e < L * AD; e += 256) {
-    const int i = e / AD, d = e % AD;
+  float* out = ctx + (long)b * L * (nH * dH) + hd * dH;
+  for (int e = threadIdx.x; e < L * dH; e += 256) {
+    const int i = e / dH, d = e % dH;
     float s = 0.f;
     for (int j = 0; j < L; ++j) s = fmaf(Ps[i * LP + j], Vs[j * ALD + d], s);
-    out[(long)i * (nH * AD) + d] = s;
+    out[(long)i * (nH * dH) + d] = s;
   }
 }
 
 // dV = P^T dO ; dP = dO V^T ; dS = P o (dP - rowsum(dP o P)) ; dQ = scale * dS K ; dK = scale * dS^T Q
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
-                                                       const float* __restrict__ dctx, int L, int nH, float scale,
+                                                       const float* __restrict__ dctx, int L, int nH, int dH, float scale,
                                                        float* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ALD = dH + 1;
   float* Qs = smem; float* Ks = Qs + L * ALD; float* Vs = Ks + L * ALD; float* Os = Vs + L * ALD;
   float* Ps = Os + L * ALD; float* Ds = Ps + L * (L + 1);  // Ps = P, Ds = dS
   const int b = blockIdx.x / nH, hd = blockIdx.x % nH;
-  const int ld = 3 * nH * AD;
-  const float* base = qkv + (long)b * L * ld + hd * AD;
-  const float* dob = dctx + (long)b * L * (nH * AD) + hd * AD;
-  for (int i = threadIdx.x; i < L * (AD / 4); i += 256) {
-    const int row = i / (AD / 4), c4 = i % (AD / 4);
+  const int ld = 3 * nH * dH;
+  const int d4 = dH / 4;
+  const float* base = qkv + (long)b * L * ld + hd * dH;
+  const float* dob = dctx + (long)b * L * (nH * dH) + hd * dH;
+  for (int i = threadIdx.x; i < L * d4; i += 256) {
+    const int row = i / d4, c4 = i % d4;
     const float4 q = *reinterpret_cast<const float4*>(base + (long)row * ld + c4 * 4);
-    const float4 k = *reinterpret_cast<const float4*>(base + (long)row * ld + nH * AD + c4 * 4);
-    const float4 v = *reinterpret_cast<const float4*>(base + (long)row * ld + 2 * nH * AD + c4 * 4);
-    const float4 o = *reinterpret_cast<const float4*>(dob + (long)row * (nH * AD) + c4 * 4);
+    const float4 k = *reinterpret_cast<const float4*>(base + (long)row * ld + nH * dH + c4 * 4);
+    const float4 v = *reinterpret_cast<const float4*>(base + (long)row * ld + 2 * nH * dH + c4 * 4);
+    const float4 o = *reinterpret_cast<const float4*>(dob + (long)row * (nH * dH) + c4 * 4);
     float* qd = Qs + row * ALD + c4 * 4; qd[0] = q.x; qd[1] = q.y; qd[2] = q.z; qd[3] = q.w;
     float* kd = Ks + row * ALD + c4 * 4; kd[0] = k.x; kd[1] = k.y; kd[2] = k.z; kd[3] = k.w;
     float* vd = Vs + row * ALD + c4 * 4; vd[0] = v.x; vd[1] = v.y; vd[2] = v.z; vd[3] = v.w;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     const int i = e / L, j = e % L;
     float s = 0.f;
 #pragma unroll 16
-    for (int d = 0; d < AD; ++d) s = fmaf(Os[i * ALD + d], Vs[j * ALD + d], s);
+    for (int d = 0; d < dH; ++d) s = fmaf(Os[i * ALD + d], Vs[j * ALD + d], s);
     Ds[i * LP + j] = s;
   }
   __syncthreads();
@@ -226,9 +229,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  float* dq = dqkv + (long)b * L * ld + hd * AD;
-  for (int e = threadIdx.x; e < L * AD; e += 256) {
-    const int i = e / AD, d = e % AD;
+  float* dq = dqkv + (long)b * L * ld + hd * dH;
+  for (int e = threadIdx.x; e < L * dH; e += 256) {
+    const int i = e / dH, d = e % dH;
     float sq = 0.f, sk = 0.f, sv = 0.f;
     for (int j = 0; j < L; ++j) {
       sq = fmaf(Ds[i * LP + j], Ks[j * ALD + d], sq);   // dQ[i] = sum_j dS[i][j] K[j]
@@ -236,8 +239,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       sv = fmaf(Ps[j * LP + i], Os[j * ALD + d], sv);   // dV[i] = sum_j P[j][i] dO[j]
     }
     dq[(long)i * ld + d] = sq;
-    dq[(long)i * ld + nH * AD + d] = sk;
-    dq[(long)i * ld + 2 * nH * AD + d] = sv;
+    dq[(long)i * ld + nH * dH + d] = sk;
+    dq[(long)i * ld + 2 * nH * dH + d] = sv;
   }
 }
 
@@ -249,7 +252,20 @@ __global__ void embed_bwd_kernel(const long* __restrict__ ids, const float* __re
   for (int c = threadIdx.x; c < H; c += blockDim.x) atomicAdd(dst + c, dx[t * H + c]);
 }
 
+// dx = dy * gelu'(pre)
+__global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, long n, float* __restrict__ dx) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = dy[i] * gelu_erf_grad(pre[i]);
+}
+
 }  // namespace
+
+extern "C" int cxrk_gelu_bwd(const float* dy, const float* pre, long n, float* dx, hipStream_t stream) {
+  CXRK_CHECK_ARG(dy && pre && dx && n > 0);
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dy, pre, n, dx);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
 
 extern "C" int cxrk_embed_ln_fwd(const long* ids, const float* word, const float* pos, const float* type,
                                  const float* gamma, const float* beta, float eps, long T, int L, int H, float* y,
@@ -296,15 +312,16 @@ extern "C" int cxrk_residual_ln_bwd(const float* dy, const float* xhat, const fl
 extern "C" int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, int nH, int dH, float* ctx, float* probs,
                              hipStream_t stream) {
   CXRK_CHECK_ARG(qkv && ctx && B > 0 && nH > 0 && aligned16(qkv));
-  if (dH != AD || L > AL || L < 1) return CXRK_ERR_UNSUPPORTED;
+  if (dH > AD || dH < 4 || (dH % 4) != 0 || L > AL || L < 1) return CXRK_ERR_UNSUPPORTED;
+  const int ALD = dH + 1;
   const size_t sh = (size_t)(3 * L * ALD + L * (L + 1)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)((3 * AL * ALD + AL * (AL + 1)) * sizeof(float)));
+                        (int)((3 * AL * (AD + 1) + AL * (AL + 1)) * sizeof(float)));
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * nH)), dim3(256), sh, stream, qkv, mask, L, nH,
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * nH)), dim3(256), sh, stream, qkv, mask, L, nH, dH,
                      1.0f / sqrtf((float)dH), ctx, probs);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
@@ -313,15 +330,16 @@ extern "C" int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, i
 extern "C" int cxrk_attn_bwd(const float* qkv, const float* probs, const float* dctx, int B, int L, int nH, int dH,
                              float* dqkv, hipStream_t stream) {
   CXRK_CHECK_ARG(qkv && probs && dctx && dqkv && B > 0 && nH > 0 && aligned16(qkv) && aligned16(dctx));
-  if (dH != AD || L > AL || L < 1) return CXRK_ERR_UNSUPPORTED;
+  if (dH > AD || dH < 4 || (dH % 4) != 0 || L > AL || L < 1) return CXRK_ERR_UNSUPPORTED;
+  const int ALD = dH + 1;
   const size_t sh = (size_t)(4 * L * ALD + 2 * L * (L + 1)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)((4 * AL * ALD + 2 * AL * (AL + 1)) * sizeof(float)));
+                        (int)((4 * AL * (AD + 1) + 2 * AL * (AL + 1)) * sizeof(float)));
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * nH)), dim3(256), sh, stream, qkv, probs, dctx, L, nH,
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * nH)), dim3(256), sh, stream, qkv, probs, dctx, L, nH, dH,
                      1.0f / sqrtf((float)dH), dqkv);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;

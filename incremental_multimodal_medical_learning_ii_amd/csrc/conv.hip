@@ -36,13 +36,14 @@ __global__ void bn_fold_kernel(const float* __restrict__ w, const float* __restr
 }
 
 // One block per output channel: dW[ko] = scale[ko] * sum_z slab_z[ko], dgamma, dbeta.
-//   dgamma[ko] = rstd[ko] * ( <w[ko], dWraw[ko]> - rmean[ko] * sumdy[ko] ),  dbeta[ko] = sumdy[ko]
-// (sum_{n,h,w} dy*z = <w, dWraw> because z is linear in w; see DESIGN.md "BatchNorm in eval mode").
+//   dbeta[ko] = sumdy[ko];  dgamma[ko] = sum dy*xhat = sumdyy[ko] / gamma[ko]  with sumdyy = sum dy*(y_bn - beta)
+//   (fallback: rstd*(<w[ko], dWraw[ko]> - rmean*sumdy), exact in exact arithmetic since z is linear in w).
 __global__ void wgrad_reduce_bn_kernel(const float* __restrict__ slabs, int nslab, long slab_stride, int taps, int C, int Cpad,
                                        const float* __restrict__ w, const float* __restrict__ scale,
                                        const float* __restrict__ rstd, const float* __restrict__ rmean,
-                                       const float* __restrict__ sumdy, float* __restrict__ dw, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int accumulate) {
+                                       const float* __restrict__ sumdy, const float* __restrict__ gamma,
+                                       const float* __restrict__ sumdyy, float* __restrict__ dw,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
   __shared__ float sh[16];
   const int ko = blockIdx.x;
   const int n = taps * Cpad;
@@ -61,7 +62,10 @@ __global__ void wgrad_reduce_bn_kernel(const float* __restrict__ slabs, int nsla
   if (dgamma) {
     dot = block_sum(dot, sh);
     if (threadIdx.x == 0) {
-      const float g = rstd[ko] * (dot - rmean[ko] * sumdy[ko]);
+      // preferred: sum dy*(y_bn - beta) / gamma (well conditioned); fallback when gamma == 0 or no y_bn is available:
+      // rstd*(<w,wgrad> - mean*sumdy), which cancels badly when the conv input has a large DC component.
+      const float g = (gamma && sumdyy && gamma[ko] != 0.f) ? sumdyy[ko] / gamma[ko]
+                                                            : rstd[ko] * (dot - rmean[ko] * sumdy[ko]);
       dgamma[ko] = accumulate ? dgamma[ko] + g : g;
       dbeta[ko] = accumulate ? dbeta[ko] + sumdy[ko] : sumdy[ko];
     }
@@ -171,7 +175,66 @@ __global__ void spatial_mean_bwd_kernel(const float* __restrict__ dy, float* __r
   for (int i = threadIdx.x; i < P * C; i += blockDim.x) dx[(long)n * P * C + i] = dy[(long)n * C + (i % C)] * inv;
 }
 
+// Per-channel reductions of the BN backward, stage 1.  Block = 4 row-lanes x 64 columns; blockIdx.y = row chunk.
+//   p0[c] = sum_r dy[r][c],   p1[c] = sum_r dy[r][c] * (y[r][c] - sub[r][c] - beta[c])
+__global__ __launch_bounds__(256) void bn_bwd_reduce_partial_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                    const float* __restrict__ sub, const float* __restrict__ beta,
+                                                                    long rows, int C, int rows_per, float* __restrict__ part) {
+  __shared__ float sh[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const long r0 = (long)blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    const float b = beta[c];
+    for (long r = r0 + rl; r < r1; r += 4) {
+      const float d = dy[r * C + c];
+      float v = y[r * C + c] - b;
+      if (sub) v -= sub[r * C + c];
+      s0 += d; s1 += d * v;
+    }
+  }
+  sh[0][rl][cl] = s0; sh[1][rl][cl] = s1;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    part[((long)blockIdx.y * 2 + 0) * C + c] = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
+    part[((long)blockIdx.y * 2 + 1) * C + c] = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
+  }
+}
+__global__ void bn_bwd_reduce_final_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ sumdy,
+                                           float* __restrict__ sumdyy) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int p = 0; p < nparts; ++p) { a += part[((long)p * 2) * C + c]; b += part[((long)p * 2 + 1) * C + c]; }
+  sumdy[c] = a; sumdyy[c] = b;
+}
+
 }  // namespace
+
+static int bn_reduce_parts(long rows, int C) {
+  const int cb = ceil_div(C, 64);
+  long np = 2048 / cb; if (np < 1) np = 1;
+  const long maxp = (rows + 63) / 64; if (np > maxp) np = maxp;
+  if (np < 1) np = 1;
+  return (int)np;
+}
+extern "C" size_t cxrk_bn_bwd_reduce_ws_bytes(long rows, int C) { return (size_t)bn_reduce_parts(rows, C) * 2 * C * sizeof(float); }
+
+extern "C" int cxrk_bn_bwd_reduce(const float* dy, const float* y, const float* sub, const float* beta, long rows, int C,
+                                  float* sumdy, float* sumdyy, float* ws, size_t ws_bytes, hipStream_t stream) {
+  CXRK_CHECK_ARG(dy && y && beta && sumdy && sumdyy && rows > 0 && C > 0);
+  int np = bn_reduce_parts(rows, C);
+  if (ws == nullptr || ws_bytes < (size_t)np * 2 * C * sizeof(float)) return CXRK_ERR_WS;
+  const int rows_per = (int)((rows + np - 1) / np);
+  np = (int)((rows + rows_per - 1) / rows_per);
+  hipLaunchKernelGGL(bn_bwd_reduce_partial_kernel, dim3(ceil_div(C, 64), np), dim3(256), 0, stream, dy, y, sub, beta, rows, C,
+                     rows_per, ws);
+  CXRK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, ws, np, C, sumdy, sumdyy);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
 
 extern "C" int cxrk_bn_fold(const float* w, const float* gamma, const float* beta, const float* rmean, const float* rvar,
                             float eps, int Ko, int taps, int C, int Cpad, float* w_scaled, float* scale, float* shift,
@@ -249,7 +312,8 @@ extern "C" size_t cxrk_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Ko, i
 // dW (+ BN parameter gradients).  x: conv input [N,H,W,Cpad]; dy: gradient w.r.t. the BN output, already ReLU-masked.
 // w: raw (unscaled) filter [Ko][R][S][C]; sumdy[ko] = sum of dy over (n,ho,wo) (cxrk_colsum).  C may be < Cpad (stem).
 extern "C" int cxrk_conv_bn_act_bwd_params(const float* x, const float* dy, const float* w, const float* scale,
-                                           const float* rstd, const float* rmean, const float* sumdy, float* dw,
+                                           const float* rstd, const float* rmean, const float* sumdy,
+                                           const float* gamma, const float* sumdyy, float* dw,
                                            float* dgamma, float* dbeta, int accumulate, int N, int H, int W, int C,
                                            int Cpad, int Ko, int R, int S, int stride, int pad, float* ws, size_t ws_bytes,
                                            hipStream_t stream) {
@@ -273,7 +337,7 @@ extern "C" int cxrk_conv_bn_act_bwd_params(const float* x, const float* dy, cons
   }
   if (rc < 0) return rc;
   hipLaunchKernelGGL(wgrad_reduce_bn_kernel, dim3(Ko), dim3(256), 0, stream, ws, rc, (long)Ko * Nc, R * S, C, Cpad, w,
-                     scale, rstd, rmean, sumdy, dw, dgamma, dbeta, accumulate);
+                     scale, rstd, rmean, sumdy, gamma, sumdyy, dw, dgamma, dbeta, accumulate);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
 }

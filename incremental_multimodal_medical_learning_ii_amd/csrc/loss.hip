@@ -221,7 +221,26 @@ __global__ void group_mean_bwd_kernel(const float* __restrict__ dout, int G, int
   din[t] = dout[g * D + d] / (float)n;
 }
 
+// out = alpha * (alpha_dev ? *alpha_dev : 1) * x * (mask_src ? mask_src > 0 : 1)
+__global__ void scale_mask_kernel(const float* __restrict__ x, const float* __restrict__ mask_src,
+                                  const float* __restrict__ alpha_dev, float alpha, long n, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = alpha_dev ? alpha * alpha_dev[0] : alpha;
+  float v = a * x[i];
+  if (mask_src) v = mask_src[i] > 0.f ? v : 0.f;
+  out[i] = v;
+}
+
 }  // namespace
+
+extern "C" int cxrk_scale_mask(const float* x, const float* mask_src, const float* alpha_dev, float alpha, long n,
+                               float* out, hipStream_t stream) {
+  CXRK_CHECK_ARG(x && out && n > 0);
+  hipLaunchKernelGGL(scale_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, mask_src, alpha_dev, alpha, n, out);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
 
 extern "C" int cxrk_l2norm_fwd(const float* x, long rows, int D, float eps, float* xhat, float* norm, hipStream_t stream) {
   CXRK_CHECK_ARG(x && xhat && rows > 0 && D > 0 && D <= 64 * NV);

@@ -43,6 +43,47 @@ def _rowmajor2d(t: torch.Tensor, name: str) -> Tuple[torch.Tensor, int]:
     return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
 
 
+class LaunchProfiler:
+    """Optional per-launch timing of the MFMA GEMM family with HIP events recorded on the launch stream
+    (bench.py's `roofline` object).  Off by default; when on, every GEMM / implicit-GEMM launch is bracketed by two
+    events and tagged with its kernel instantiation and algorithmic FLOPs (2*M*N*K)."""
+
+    def __init__(self):
+        self.on = False
+        self.rows = []  # (key, flops, start_event, end_event)
+
+    def start(self):
+        self.on, self.rows = True, []
+
+    def stop(self):
+        self.on = False
+
+    def bracket(self, key: str, flops: float):
+        if not self.on:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        self.rows.append((key, flops, a, b))
+        return b
+
+    def summary(self):
+        """{kernel: {"launches", "flops", "ms"}} — call after torch.cuda.synchronize()."""
+        out = {}
+        for key, flops, a, b in self.rows:
+            d = out.setdefault(key, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += a.elapsed_time(b)
+        return out
+
+
+profiler = LaunchProfiler()
+
+
+def _tile(M: int, N: int) -> str:
+    return "4,1" if N <= 64 else ("1,4" if M <= 64 else "2,2")
+
+
 class _Workspace:
     """Grow-on-demand scratch buffer per device; reuse is safe because all kernels run stream-ordered."""
 
@@ -98,9 +139,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K:
         wsb = lib.cxrk_gemm_splitk_ws_bytes(M, N, splitk)
         ws = workspace(wsb, out.device)
         wsb = ws.numel() * 4
+    ev = profiler.bracket(f"gemm_f32_kernel<Dense{'MC' if trans_a else 'KC'},Dense{'KC' if trans_b else 'MC'},{_tile(M, N)}>",
+                          2.0 * M * N * K) if profiler.on else None
     rc = lib.cxrk_gemm_f32(int(trans_a), int(trans_b), M, N, K, _p(a), lda, _p(b), ldb, _p(out), ldc, _p(bias),
                            _p(residual), ldr, _p(aux), ldaux, auxmode, _p(preact_out), ldc2, act, float(alpha),
                            int(accumulate), int(splitk), _p(ws), wsb, _stream())
+    if ev is not None:
+        ev.record()
     check(rc, f"cxrk_gemm_f32(M={M},N={N},K={K},tA={trans_a},tB={trans_b})")
     return out
 
@@ -169,29 +214,61 @@ def bn_fold(w, gamma, beta, rmean, rvar, eps, Ko, taps, C, Cpad, w_scaled, scale
 
 def conv_fwd(x, w_scaled, shift, residual, y, N, H, W, C, Ko, R, S, stride, pad, relu):
     lib = _lib.load()
-    check(lib.cxrk_conv_bn_act_fwd(_p(_chk(x, "conv.x")), _p(w_scaled), _p(shift), _p(residual), _p(y), N, H, W, C, Ko,
-                                   R, S, stride, pad, int(relu), _stream()),
-          f"cxrk_conv_bn_act_fwd(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
+    ev = None
+    if profiler.on:
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        ev = profiler.bracket(f"gemm_f32_kernel<ConvIm2colKC,DenseKC,{'4,1' if Ko <= 64 else '2,2'}>",
+                              2.0 * N * Ho * Wo * Ko * R * S * C)
+    rc = lib.cxrk_conv_bn_act_fwd(_p(_chk(x, "conv.x")), _p(w_scaled), _p(shift), _p(residual), _p(y), N, H, W, C, Ko,
+                                  R, S, stride, pad, int(relu), _stream())
+    if ev is not None:
+        ev.record()
+    check(rc, f"cxrk_conv_bn_act_fwd(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
     return y
 
 
 def conv_bwd_data(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R, S, stride, pad):
     lib = _lib.load()
-    check(lib.cxrk_conv_bn_act_bwd_data(_p(_chk(dy, "conv.dy")), _p(w_scaled), _p(residual), _p(relu_src), _p(dx), N, H,
-                                        W, C, Ko, R, S, stride, pad, _stream()),
-          f"cxrk_conv_bn_act_bwd_data(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
+    ev = None
+    if profiler.on:  # algorithmic FLOPs of a data gradient = those of the forward conv (stride-2 zero taps are waste)
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        ev = profiler.bracket(f"gemm_f32_kernel<ConvDgradKC,ConvFilterMC,{'4,1' if C <= 64 else '2,2'}>",
+                              2.0 * N * Ho * Wo * Ko * R * S * C)
+    rc = lib.cxrk_conv_bn_act_bwd_data(_p(_chk(dy, "conv.dy")), _p(w_scaled), _p(residual), _p(relu_src), _p(dx), N, H,
+                                       W, C, Ko, R, S, stride, pad, _stream())
+    if ev is not None:
+        ev.record()
+    check(rc, f"cxrk_conv_bn_act_bwd_data(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
     return dx
 
 
-def conv_bwd_params(x, dy, w, scale, rstd, rmean, sumdy, dw, dgamma, dbeta, accumulate, N, H, W, C, Cpad, Ko, R, S,
-                    stride, pad):
+def bn_bwd_reduce(dy, y, sub, beta, sumdy, sumdyy):
+    """sumdy[c] = sum dy; sumdyy[c] = sum dy*(y - sub - beta[c]) over all rows of the [rows, C] views."""
+    lib = _lib.load()
+    C = dy.shape[-1]
+    rows = dy.numel() // C
+    ws = workspace(lib.cxrk_bn_bwd_reduce_ws_bytes(rows, C), dy.device)
+    check(lib.cxrk_bn_bwd_reduce(_p(_chk(dy, "bn_reduce.dy")), _p(_chk(y, "bn_reduce.y")), _p(sub), _p(beta), rows, C,
+                                 _p(sumdy), _p(sumdyy), _p(ws), ws.numel() * 4, _stream()), "cxrk_bn_bwd_reduce")
+
+
+def conv_bwd_params(x, dy, w, scale, rstd, rmean, sumdy, gamma, sumdyy, dw, dgamma, dbeta, accumulate, N, H, W, C, Cpad,
+                    Ko, R, S, stride, pad):
     lib = _lib.load()
     wsb = lib.cxrk_conv_wgrad_ws_bytes(N, H, W, Cpad, Ko, R, S, stride, pad)
     ws = workspace(wsb, x.device)
+    ev = None
+    if profiler.on:
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        ev = profiler.bracket(f"gemm_f32_kernel<DenseMC,ConvIm2colMC,{'1,4' if Ko <= 64 else '2,2'}>",
+                              2.0 * N * Ho * Wo * Ko * R * S * Cpad)
     check(lib.cxrk_conv_bn_act_bwd_params(_p(_chk(x, "conv.x")), _p(_chk(dy, "conv.dy")), _p(w), _p(scale), _p(rstd),
-                                          _p(rmean), _p(sumdy), _p(dw), _p(dgamma), _p(dbeta), int(accumulate), N, H, W,
+                                          _p(rmean), _p(sumdy), _p(gamma), _p(sumdyy), _p(dw), _p(dgamma), _p(dbeta),
+                                          int(accumulate), N, H, W,
                                           C, Cpad, Ko, R, S, stride, pad, _p(ws), ws.numel() * 4, _stream()),
           f"cxrk_conv_bn_act_bwd_params(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
+    if ev is not None:
+        ev.record()
 
 
 def nchw_to_nhwc(x: torch.Tensor, cpad: int) -> torch.Tensor:
@@ -315,6 +392,13 @@ def embed_bwd(ids, dx, dword):
     check(lib.cxrk_embed_bwd(_p(ids), _p(_chk(dx, "embed.dx")), T, H, _p(dword), _stream()), "cxrk_embed_bwd")
 
 
+def gelu_bwd(dy, pre):
+    lib = _lib.load()
+    dx = torch.empty_like(pre)
+    check(lib.cxrk_gelu_bwd(_p(_chk(dy.contiguous(), "gelu.dy")), _p(pre), pre.numel(), _p(dx), _stream()), "cxrk_gelu_bwd")
+    return dx
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # heads
 # ----------------------------------------------------------------------------------------------------------------
@@ -415,6 +499,17 @@ def eval_score(cosv, pred_diff: bool = False):
     check(lib.cxrk_eval_score(_p(_chk(cosv, "eval.cos")), B, C, int(pred_diff), _p(score), _p(pred), _stream()),
           "cxrk_eval_score")
     return score, pred
+
+
+def scale_mask(x, mask_src=None, alpha_dev=None, alpha: float = 1.0, out=None):
+    """out = alpha * (*alpha_dev) * x * (mask_src > 0); alpha_dev is a 0-d device tensor (no host sync)."""
+    lib = _lib.load()
+    x = _chk(x, "scale_mask.x").contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.cxrk_scale_mask(_p(x), _p(mask_src), _p(alpha_dev), float(alpha), x.numel(), _p(out), _stream()),
+          "cxrk_scale_mask")
+    return out
 
 
 def group_mean_fwd(x, G, n):

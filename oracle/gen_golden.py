@@ -53,7 +53,7 @@ def load_reference_text():
 
 
 def np_(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()  # copy: parameters are updated in place after being recorded
 
 
 def relerr(a, b):

@@ -26,46 +26,76 @@ PLANES = (64, 128, 256, 512)
 BN_EPS = 1e-5
 
 
+class ReluPolicy:
+    """ReLU with optionally imposed decisions.
+
+    A ReLU network's gradient is discontinuous where a pre-activation is exactly at zero: two correct fp32
+    implementations whose forward values differ in the last bit can take different sides of the kink for a handful of
+    the ~5M activations of a ResNet-50 pass, and that single 0/1 decision then shifts every upstream gradient at the
+    1e-3 level.  For gradient parity the oracle can therefore be run with the decisions (`masks`, in execution
+    order: stem, then relu1/relu2/relu_out of every bottleneck, then the projector) taken from the implementation under
+    test; `flips` / `max_flip_rel` then report how many decisions differ from the oracle's own and how close to zero
+    (relative to the layer's max |pre-activation|) those pre-activations are."""
+
+    def __init__(self, masks=None):
+        self.masks, self.i, self.flips, self.count, self.max_flip_rel = masks, 0, 0, 0, 0.0
+
+    def __call__(self, z: torch.Tensor) -> torch.Tensor:
+        if self.masks is None:
+            return F.relu(z)
+        m = self.masks[self.i].to(z.device)
+        self.i += 1
+        diff = (z > 0) != m
+        self.count += m.numel()
+        if diff.any():
+            self.flips += int(diff.sum())
+            self.max_flip_rel = max(self.max_flip_rel, float(z[diff].abs().max() / z.abs().max()))
+        return z * m.to(z.dtype)
+
+
+_PLAIN = ReluPolicy()
+
+
 def _bn(p: P, name: str, x: torch.Tensor, training: bool = False) -> torch.Tensor:
     return F.batch_norm(x, p[name + ".running_mean"], p[name + ".running_var"], p[name + ".weight"],
                         p[name + ".bias"], training=training, eps=BN_EPS)
 
 
-def bottleneck(p: P, pre: str, x: torch.Tensor, stride: int, has_down: bool) -> torch.Tensor:
+def bottleneck(p: P, pre: str, x: torch.Tensor, stride: int, has_down: bool, relu=_PLAIN) -> torch.Tensor:
     idt = x
-    o = F.relu(_bn(p, pre + "bn1", F.conv2d(x, p[pre + "conv1.weight"])))
-    o = F.relu(_bn(p, pre + "bn2", F.conv2d(o, p[pre + "conv2.weight"], stride=stride, padding=1)))
+    o = relu(_bn(p, pre + "bn1", F.conv2d(x, p[pre + "conv1.weight"])))
+    o = relu(_bn(p, pre + "bn2", F.conv2d(o, p[pre + "conv2.weight"], stride=stride, padding=1)))
     o = _bn(p, pre + "bn3", F.conv2d(o, p[pre + "conv3.weight"]))
     if has_down:
         idt = _bn(p, pre + "downsample.1", F.conv2d(x, p[pre + "downsample.0.weight"], stride=stride))
-    return F.relu(o + idt)
+    return relu(o + idt)
 
 
-def resnet50_trunk(p: P, x: torch.Tensor, prefix: str = "encoder.encoder.", collect: List = None) -> torch.Tensor:
+def resnet50_trunk(p: P, x: torch.Tensor, prefix: str = "encoder.encoder.", collect: List = None, relu=_PLAIN) -> torch.Tensor:
     x = F.conv2d(x, p[prefix + "conv1.weight"], stride=2, padding=3)
-    x = F.relu(_bn(p, prefix + "bn1", x))
+    x = relu(_bn(p, prefix + "bn1", x))
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
     if collect is not None:
         collect.append(x)
     for li, (nblk, planes) in enumerate(zip(LAYERS, PLANES), start=1):
         for b in range(nblk):
             stride = 2 if (b == 0 and li > 1) else 1
-            x = bottleneck(p, f"{prefix}layer{li}.{b}.", x, stride, has_down=(b == 0))
+            x = bottleneck(p, f"{prefix}layer{li}.{b}.", x, stride, has_down=(b == 0), relu=relu)
         if collect is not None:
             collect.append(x)
     return x
 
 
-def projector(p: P, patch: torch.Tensor, prefix: str = "projector.model.") -> torch.Tensor:
+def projector(p: P, patch: torch.Tensor, prefix: str = "projector.model.", relu=_PLAIN) -> torch.Tensor:
     h = F.conv2d(patch, p[prefix + "0.weight"])
-    h = F.relu(_bn(p, prefix + "1", h))
+    h = relu(_bn(p, prefix + "1", h))
     return F.conv2d(h, p[prefix + "3.weight"], p[prefix + "3.bias"])
 
 
-def image_model_forward(p: P, x: torch.Tensor, collect: List = None) -> torch.Tensor:
+def image_model_forward(p: P, x: torch.Tensor, collect: List = None, relu=_PLAIN) -> torch.Tensor:
     """`ImageModel.forward` (model.py:141-154): returns the projected global embedding [B,128]."""
-    patch = resnet50_trunk(p, x, collect=collect)
-    proj = projector(p, patch)
+    patch = resnet50_trunk(p, x, collect=collect, relu=relu)
+    proj = projector(p, patch, relu=relu)
     return proj.mean(dim=(2, 3))
 
 

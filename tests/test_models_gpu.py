@@ -1,0 +1,277 @@
+"""Model-level parity on the MI355X: the HIP-backed reference-API classes against the committed golden fixtures
+(produced by the reference's own modules where importable, see oracle/gen_golden.py) and against the CPU oracle
+on seeded inputs.  Tolerance: 1e-3 relative (north star), stated per check; fp32 kernels land ~1e-5."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from incremental_multimodal_medical_learning_ii_amd import functional as Fh  # noqa: E402
+from incremental_multimodal_medical_learning_ii_amd import optim as cxr_optim  # noqa: E402
+from incremental_multimodal_medical_learning_ii_amd import synthetic as syn  # noqa: E402
+from incremental_multimodal_medical_learning_ii_amd.health_multimodal.image.model import get_biovil_resnet  # noqa: E402
+from incremental_multimodal_medical_learning_ii_amd.health_multimodal.text import CXRBertConfig, CXRBertModel  # noqa: E402
+from incremental_multimodal_medical_learning_ii_amd.models import myLinearModel, myMLP  # noqa: E402
+
+DEV = "cuda"
+TOL = 1e-3
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().float().cpu()
+    b = torch.as_tensor(b).detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.isfinite(a).all()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def T(x):
+    return torch.from_numpy(np.asarray(x))
+
+
+# ------------------------------------------------------------------------------------------------ text
+def test_text_tiny_forward_backward_vs_reference(golden_dir):
+    g = np.load(f"{golden_dir}/g1_text_tiny.npz")
+    cfg = CXRBertConfig(vocab_size=128, hidden_size=64, num_attention_heads=4, intermediate_size=256,
+                        num_hidden_layers=2, max_position_embeddings=64, projection_size=128)
+    model = CXRBertModel(cfg).eval()
+    sd = {k[3:]: T(g[k]) for k in g.files if k.startswith("w::")}
+    res = model.load_state_dict(sd, strict=False)
+    assert not [k for k in res.missing_keys if "position_ids" not in k], res.missing_keys
+    model.to(DEV)
+    ids = T(g["ids"]).to(DEV)
+    for tag in ("full", "ragged"):
+        mask = T(g["mask_" + tag]).to(DEV)
+        out = model(ids, mask, output_cls_projected_embedding=True, return_dict=True)
+        assert rel(out.cls_projected_embedding, g["proj_" + tag]) < TOL
+        assert rel(out.last_hidden_state[:, 0], g["last_hidden_" + tag][:, 0]) < TOL
+        assert rel(out.logits[:, 0], g["mlm_logits_cls_" + tag]) < TOL
+        tup = model(ids, mask, output_cls_projected_embedding=True, return_dict=False)
+        assert len(tup) == 5 and torch.equal(tup[2], out.cls_projected_embedding)
+    # backward through the whole encoder (fixture: gradients of the reference model for sum(proj * probe))
+    model.zero_grad()
+    proj = model.get_projected_text_embeddings(ids, T(g["mask_ragged"]).to(DEV), normalize_embeddings=False)
+    (proj * T(g["probe"]).to(DEV)).sum().backward()
+    named = dict(model.named_parameters())
+    checked = 0
+    for k in g.files:
+        if not k.startswith("g::"):
+            continue
+        name = k[3:]
+        ref = T(g[k])
+        if name.startswith("cls.predictions"):
+            continue
+        got = named[name].grad
+        assert got is not None, name
+        if ref.abs().max() < 1e-5:  # analytically zero (e.g. key bias: softmax is shift-invariant) -> rounding noise
+            assert got.abs().max() < 1e-5, name
+        else:
+            assert rel(got, ref) < TOL, (name, rel(got, ref))
+        checked += 1
+    assert checked >= 40
+
+
+def test_text_full_config_vs_reference(golden_dir):
+    g = np.load(f"{golden_dir}/g1_text_full.npz")
+    model = CXRBertModel(CXRBertConfig()).eval()
+    syn.fill_module_(model)
+    model.to(DEV)
+    ids = T(g["ids"]).to(DEV)
+    for tag, mask in (("full", torch.ones(4, 32, dtype=torch.int64)), ("ragged", T(g["mask_ragged"]))):
+        emb = model.get_projected_text_embeddings(ids, mask.to(DEV), normalize_embeddings=False)
+        assert rel(emb, g["proj_" + tag]) < TOL, rel(emb, g["proj_" + tag])
+    n = model.get_projected_text_embeddings(ids, torch.ones_like(ids), normalize_embeddings=True)
+    assert rel(n.norm(dim=1), torch.ones(4)) < 1e-5
+
+
+def test_text_engine_api():
+    from incremental_multimodal_medical_learning_ii_amd.health_multimodal.text import SyntheticTokenizer, TextInferenceEngine
+    cfg = CXRBertConfig(vocab_size=512, hidden_size=128, num_attention_heads=2, intermediate_size=256,
+                        num_hidden_layers=1, max_position_embeddings=16)
+    model = CXRBertModel(cfg)
+    syn.fill_module_(model)
+    eng = TextInferenceEngine(SyntheticTokenizer(512), model.eval().to(DEV))
+    e = eng.get_embeddings_from_prompt(["No pleural effusion.", "There is cardiomegaly"], normalize=False, verbose=False)
+    assert e.shape == (2, 128) and e.is_cuda and not e.requires_grad
+    with pytest.raises(ValueError):
+        eng.get_embeddings_from_prompt("bad [SEP] prompt")
+    with pytest.raises(ValueError):
+        eng.get_embeddings_from_prompt(" ".join(["w"] * 40))  # longer than max_position_embeddings
+    model.train()
+    with pytest.raises(AssertionError):
+        eng.get_embeddings_from_prompt("x")
+    model.eval()
+    sims = eng.get_pairwise_similarities(["a b", "c d"], ["a b", "e f g"])
+    assert abs(sims[0].item() - 1.0) < 1e-5
+    toks = eng.predict_masked_tokens("there is [MASK] effusion")
+    assert len(toks) == 1 and len(toks[0]) == 1
+
+
+# ------------------------------------------------------------------------------------------------ image
+def _image_oracle_with_decisions(model_cpu_sd, x, probe, masks):
+    """CPU oracle gradients under the ReLU decisions of the implementation under test (oracle/ref_image.ReluPolicy)."""
+    from oracle import ref_image
+    p = {k: v.detach().clone() for k, v in model_cpu_sd.items()}
+    for k, v in p.items():
+        if v.is_floating_point() and "running" not in k and ".fc." not in k:
+            v.requires_grad_(True)
+    pol = ref_image.ReluPolicy(masks)
+    emb = ref_image.image_model_forward(p, x, relu=pol)
+    (emb * probe).sum().backward()
+    return emb.detach(), {k: v.grad for k, v in p.items() if v.requires_grad}, pol
+
+
+def test_image_model_forward_backward(golden_dir):
+    from incremental_multimodal_medical_learning_ii_amd import image_encoder as IE
+    g = np.load(f"{golden_dir}/g3_image.npz")
+    model = get_biovil_resnet(None)
+    syn.fill_module_(model)
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).eval()
+    x = syn.synthetic_images(2, 224, seed=27)
+    emb = model(x.to(DEV))
+    assert emb.shape == (2, 128)
+    assert rel(emb, g["emb"]) < TOL, rel(emb, g["emb"])                      # forward vs the committed fixture
+    masks = IE.relu_decisions(IE.ImageEncodeFn.last_state)
+    probe = T(g["probe"])
+    (emb * probe.to(DEV)).sum().backward()
+    named = dict(model.named_parameters())
+    # (1) rigorous gradient parity: oracle run under the same ReLU decisions -> every tensor within 1e-3
+    _, gref, pol = _image_oracle_with_decisions(sd_cpu, x, probe, masks)
+    assert pol.count > 5_000_000 and pol.flips <= 20 and pol.max_flip_rel < 1e-5, (pol.flips, pol.max_flip_rel)
+    worst = max(((rel(named[k].grad, v), k) for k, v in gref.items()), key=lambda t: t[0])
+    assert worst[0] < TOL, worst
+    # (2) against the committed fixture (oracle's own decisions): a kink flip moves upstream gradients by ~1e-3,
+    #     so only a loose bound holds for every tensor; the tight bound must hold for the tensors downstream of any flip.
+    errs = {k[7:]: abs(named[k[7:]].grad.double().norm().item() - float(g[k])) / max(float(g[k]), 1e-30)
+            for k in g.files if k.startswith("gnorm::") and "fc." not in k}
+    assert max(errs.values()) < 3e-2, max(errs.items(), key=lambda t: t[1])
+    assert errs["projector.model.3.weight"] < 1e-5 and errs["encoder.encoder.layer4.2.conv3.weight"] < 1e-4
+    assert rel(named["projector.model.3.bias"].grad, g["g::projector.model.3.bias"]) < 1e-5
+    # projector pinned against the reference's modules.MLP: patch embeddings API
+    with torch.no_grad():
+        patches = model.get_patchwise_projected_embeddings(x.to(DEV), normalize=True)
+    assert patches.shape == (2, 7, 7, 128)
+    assert rel(patches.norm(dim=-1), torch.ones(2, 7, 7)) < 1e-5
+    model.freeze_encoder = True
+    assert not model(x.to(DEV)).requires_grad
+
+
+def test_image_model_rejects_cpu_and_bad_input():
+    model = get_biovil_resnet(None)
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 3, 32, 32))
+    model.to(DEV)
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 1, 32, 32, device=DEV))
+
+
+# ------------------------------------------------------------------------------------------------ adapters / T-ref
+def _load_adapter(mod, g, prefix, step):
+    mod.load_state_dict({k.split(prefix)[1]: T(g[k]) for k in g.files if k.startswith(f"w{step}::{prefix}")})
+
+
+def test_adapter_step_vs_reference_models(golden_dir):
+    g = np.load(f"{golden_dir}/g2_adapter_step.npz")
+    img_ad, txt_ad = myMLP(), myMLP()
+    _load_adapter(img_ad, g, "image_adapter.", 0)
+    _load_adapter(txt_ad, g, "text_adapter.", 0)
+    img_ad.to(DEV), txt_ad.to(DEV)
+    embs, labels, bert_out = (T(g[k]).to(DEV) for k in ("embs", "labels", "bert_out"))
+    opt = cxr_optim.Adam(list(txt_ad.parameters()) + list(img_ad.parameters()), lr=1e-4)
+    for step in (1, 2, 3):
+        opt.zero_grad()
+        new_embs = img_ad(embs)
+        pv = Fh.group_mean(txt_ad(bert_out.reshape(40, 128)), 10, 4)
+        cos = Fh.pairwise_cosine_similarity(new_embs, pv)
+        loss, logits = Fh.posneg_bce_loss(cos, labels)
+        loss.backward()
+        if step == 1:
+            assert rel(logits, g["logits_step1"]) < TOL
+            for k in g.files:
+                if k.startswith("g1::"):
+                    mod, name = (img_ad, k[len("g1::image_adapter."):]) if "image_adapter" in k else (txt_ad, k[len("g1::text_adapter."):])
+                    assert rel(dict(mod.named_parameters())[name].grad, g[k]) < TOL, k
+        opt.step()
+        assert abs(loss.item() - float(g[f"loss_step{step}"])) < 1e-5
+        if step in (1, 3):
+            for k in g.files:
+                if k.startswith(f"w{step}::"):
+                    mod, name = (img_ad, k.split("image_adapter.")[1]) if "image_adapter" in k else (txt_ad, k.split("text_adapter.")[1])
+                    assert rel(mod.state_dict()[name], g[k]) < 1e-5, k
+    lin = myLinearModel()
+    syn.fill_module_(lin, "dense_adapter.")
+    assert rel(lin.to(DEV)(embs), g["dense_out"]) < TOL
+
+
+def test_infonce_and_zeroshot(golden_dir):
+    g = np.load(f"{golden_dir}/g4_infonce.npz")
+    for tau in (1.0, 0.07):
+        I = T(g["I"]).to(DEV).requires_grad_(True)
+        Tt = T(g["T"]).to(DEV).requires_grad_(True)
+        loss = Fh.infonce_loss(I, Tt, tau)
+        loss.backward()
+        tag = f"tau{tau}"
+        assert abs(loss.item() - float(g["loss_" + tag])) / float(g["loss_" + tag]) < TOL
+        assert rel(I.grad, g["dI_" + tag]) < TOL
+        assert rel(Tt.grad, g["dT_" + tag]) < TOL
+        assert rel(Fh.similarity_logits(I.detach(), Tt.detach(), tau), g["S_" + tag]) < TOL
+    z = np.load(f"{golden_dir}/g5_zeroshot.npz")
+    txt = Fh.group_mean(T(z["txt"]).to(DEV).reshape(20, 128), 5, 4)
+    sc = Fh.similarity_logits(T(z["img"]).to(DEV), txt)
+    assert rel(sc, z["scores"]) < TOL
+    assert torch.equal(sc.argmax(1).cpu(), T(z["argmax"]))
+
+
+# ------------------------------------------------------------------------------------------------ joint step vs oracle
+def test_joint_step_vs_cpu_oracle():
+    from oracle import ref_image, ref_step
+    from incremental_multimodal_medical_learning_ii_amd import image_encoder as IE
+    from incremental_multimodal_medical_learning_ii_amd.contrastive import JointContrastiveTrainer
+    B, L, tau = 4, 16, 0.07
+    cfg = CXRBertConfig(vocab_size=300, hidden_size=128, num_attention_heads=2, intermediate_size=256,
+                        num_hidden_layers=2, max_position_embeddings=32)
+    tm = CXRBertModel(cfg).eval()
+    im = get_biovil_resnet(None).eval()
+    syn.fill_module_(tm)
+    syn.fill_module_(im)
+    images = syn.synthetic_images(B, 64, seed=3)
+    ids, mask = syn.synthetic_tokens(B, L, vocab=300, seed=4, ragged=True)
+    ip = {k: v.detach().clone() for k, v in im.state_dict().items()}
+    tp = {k: v.detach().clone() for k, v in tm.state_dict().items()}
+    # device: one full step (forward, InfoNCE, hand-written backward, fused Adam)
+    tr = JointContrastiveTrainer(im.to(DEV), tm.to(DEV), lr=1e-4, temperature=tau)
+    tr.optimizer.zero_grad()
+    loss = tr.forward_loss(images.to(DEV), ids.to(DEV), mask.to(DEV))
+    masks = IE.relu_decisions(IE.ImageEncodeFn.last_state)
+    loss.backward()
+    grads_dev = {("i", n): p.grad.detach().clone() for n, p in im.named_parameters() if p.grad is not None}
+    grads_dev.update({("t", n): p.grad.detach().clone() for n, p in tm.named_parameters() if p.grad is not None})
+    tr.optimizer.step()
+    # CPU oracle: autograd over the restated modules under the same ReLU decisions, torch.optim.Adam
+    leaves = []
+    for d in (ip, tp):
+        for k, v in d.items():
+            if v.dtype == torch.float32 and "running" not in k and not k.startswith("cls.predictions") and ".fc." not in k:
+                v.requires_grad_(True)
+                leaves.append(v)
+    opt = torch.optim.Adam(leaves, lr=1e-4)
+    pol = ref_image.ReluPolicy(masks)
+    loss_ref = ref_step.joint_step(ip, tp, images, ids, mask, tau, opt, n_layers=2, n_heads=2, relu=pol)
+    assert pol.flips <= 5 and pol.max_flip_rel < 1e-5
+    assert abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()) < TOL, (loss.item(), loss_ref.item())
+    worst = ("", 0.0)
+    for (side, n), gdev in grads_dev.items():
+        ref = (ip if side == "i" else tp)[n].grad
+        if ref is None or ref.abs().max() < 1e-6:
+            continue
+        e = rel(gdev, ref)
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] < TOL, worst
+    isd, tsd = im.state_dict(), tm.state_dict()
+    for d, sd in ((ip, isd), (tp, tsd)):
+        for k, v in d.items():
+            if v.requires_grad:
+                assert rel(sd[k], v) < TOL, k
