@@ -29,6 +29,38 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak F
 FLOP_PER_PAIR_STEP = 41.1e9     # 3 x (8.2 GFLOP ResNet-50+projector + 5.5 GFLOP CXR-BERT, L=32, no MLM head); SURVEY.md §8d
 
 
+def log(msg: str) -> None:
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def usable_cores() -> int:
+    """Host threads this process may really use: min(affinity mask, cgroup CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, int(os.environ.get("CXRK_CPU_THREADS", "64"))))
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -49,12 +81,9 @@ def cpu_baseline(batch: int, seq_len: int, image_size: int, tau: float):
     a global batch of `batch` pairs, 1 warm-up + 2 timed steps."""
     from incremental_multimodal_medical_learning_ii_amd import synthetic as syn
     from oracle import ref_image, ref_step, ref_text
-    ncores = os.cpu_count() or 1
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    ncores = usable_cores()
     torch.set_num_threads(ncores)
+    log(f"cpu baseline: oracle joint step on {ncores} host threads, batch {batch}")
     prm, buf = ref_image.image_param_shapes()
     g = torch.Generator().manual_seed(27)
     ip = {k: (torch.randn(s, generator=g) * (0.05 if len(s) > 1 else 0.0) + (1.0 if len(s) == 1 else 0.0)) for k, s in prm.items()}
@@ -67,6 +96,7 @@ def cpu_baseline(batch: int, seq_len: int, image_size: int, tau: float):
     images = syn.synthetic_images(batch, image_size)
     ids, mask = syn.synthetic_tokens(batch, seq_len)
     ref_step.joint_step(ip, tp, images, ids, mask, tau, opt)
+    log("cpu baseline: warm-up step done")
     t0 = time.perf_counter()
     n = 2
     for _ in range(n):
@@ -80,6 +110,10 @@ def cpu_baseline(batch: int, seq_len: int, image_size: int, tau: float):
 
 def main():
     args = parse()
+    import faulthandler
+    faulthandler.enable()
+    faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)   # a stuck phase shows where it is stuck
+    torch.set_num_threads(min(usable_cores(), 16))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -99,6 +133,7 @@ def main():
     from incremental_multimodal_medical_learning_ii_amd.health_multimodal.image.model import get_biovil_resnet
     from incremental_multimodal_medical_learning_ii_amd.health_multimodal.text import CXRBertConfig, CXRBertModel
 
+    log(f"building models (world={world}, batch/gpu={args.batch_per_gpu})")
     torch.manual_seed(27)                       # identical replicas on every rank
     im = get_biovil_resnet(None).eval()         # BN on running statistics (the reference's only mode)
     tm = CXRBertModel(CXRBertConfig()).eval()   # dropout inactive
@@ -114,9 +149,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log("models + synthetic batch resident on the GPU; warm-up")
     loss = None
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         loss = trainer.step(images, ids, mask)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i + 1}/{args.warmup} done, loss {float(loss):.4f}, "
+            f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     sync()
     prof = (not args.no_roofline) and rank == 0
     if prof:
@@ -127,6 +166,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     K.profiler.stop()
+    log(f"timed region: {args.steps} steps in {dt:.2f} s")
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -153,6 +193,9 @@ def main():
         if prof:
             summ = K.profiler.summary()
             if summ:
+                for k_, v_ in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+                    log(f"  {k_:58s} {v_['launches'] / args.steps:6.1f} launches/step {v_['ms'] / args.steps:8.2f} ms/step "
+                        f"{v_['flops'] / (v_['ms'] * 1e-3) / 1e12:6.1f} TFLOP/s")
                 key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
                 achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 tot_ms = sum(v["ms"] for v in summ.values())
@@ -170,6 +213,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch, args.seq_len, args.image_size, args.temperature)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        faulthandler.cancel_dump_traceback_later()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

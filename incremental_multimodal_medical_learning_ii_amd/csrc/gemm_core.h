@@ -12,8 +12,8 @@
 // * "Loaders" turn an (idx, k) tile coordinate into global addresses: dense K-contiguous, dense idx-contiguous,
 //   and the three NHWC convolution gathers (im2col for fprop, strided-tap gather for dgrad, pixel gather for
 //   wgrad).  All of them load 16 B per lane.
-// * blockIdx -> tile mapping is XCD-aware: the 8 XCDs each walk their own M panels and visit all N tiles of a
-//   panel back to back, so the A panel is re-read from that XCD's L2 rather than from HBM.
+// * blockIdx -> tile mapping is XCD-aware (bijective T1 remap): each XCD owns a contiguous chunk of the M-panel-major
+//   tile list, so the A panel is re-read from that XCD's L2 rather than from HBM.
 #pragma once
 #include "cxrk_common.h"
 
@@ -215,6 +215,8 @@ struct ConvFilterMC {
 };
 
 // wgrad B operand: k = (n,ho,wo), idx = (r,s,c) -> x[n][ho*st-pad+r][wo*st-pad+s][c]   (c contiguous)
+// The pixel index k only ever advances by BK between consecutive load() calls, so (n,ho,wo) is carried in
+// registers and stepped with add/compare instead of being re-derived with integer divisions every K-tile.
 template <int TILE>
 struct ConvIm2colMC {
   static constexpr int NV = TILE / 32;
@@ -222,6 +224,7 @@ struct ConvIm2colMC {
   static constexpr int RPP = NTHREADS / VPR;
   struct P { const float* x; ConvGeom g; int cols; int K; };
   const float* x; int c4, kr0, K, H, W, C, Ho, Wo, st, dh, dw; long coff; bool ok;
+  int pn[NV], pho[NV], pwo[NV], knext;
   __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
     c4 = tid % VPR; kr0 = tid / VPR; K = p.K; x = p.x; H = p.g.H; W = p.g.W; C = p.g.C; Ho = p.g.Ho; Wo = p.g.Wo; st = p.g.stride;
     const int col = idx0 + c4 * 4;
@@ -229,16 +232,30 @@ struct ConvIm2colMC {
     const int tap = col / C, c = col - tap * C;
     const int r = tap / p.g.S, s = tap - r * p.g.S;
     dh = r - p.g.pad; dw = s - p.g.pad; coff = c;
+    knext = -1;
   }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
+  __device__ __forceinline__ void seek(int k0) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int k = k0 + kr0 + j * RPP;
-      const int wo = k % Wo; const int t = k / Wo; const int ho = t % Ho; const int n = t / Ho;
-      const int hi = ho * st + dh, wi = wo * st + dw;
-      const bool in = ok && (k < K) && ((unsigned)hi < (unsigned)H) && ((unsigned)wi < (unsigned)W);
-      v[j] = in ? *reinterpret_cast<const float4*>(x + (((long)n * H + hi) * W + wi) * C + coff) : zero4();
+      pwo[j] = k % Wo; const int t = k / Wo; pho[j] = t % Ho; pn[j] = t / Ho;
     }
+    knext = k0;
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
+    if (k0 != knext) seek(k0);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int k = k0 + kr0 + j * RPP;
+      const int hi = pho[j] * st + dh, wi = pwo[j] * st + dw;
+      const bool in = ok && (k < K) && ((unsigned)hi < (unsigned)H) && ((unsigned)wi < (unsigned)W);
+      v[j] = in ? *reinterpret_cast<const float4*>(x + (((long)pn[j] * H + hi) * W + wi) * C + coff) : zero4();
+      // advance this row's pixel by BK for the next K-tile
+      int wo = pwo[j] + BK, ho = pho[j], n = pn[j];
+      while (wo >= Wo) { wo -= Wo; if (++ho == Ho) { ho = 0; ++n; } }
+      pwo[j] = wo; pho[j] = ho; pn[j] = n;
+    }
+    knext = k0 + BK;
   }
   __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
 #pragma unroll
@@ -257,12 +274,17 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_f32_kernel(typename LA::P pa
   __shared__ __attribute__((aligned(16))) float As[BK * (BM + LPAD)];
   __shared__ __attribute__((aligned(16))) float Bs[BK * (BN + LPAD)];
 
-  // XCD-aware tile mapping: blocks b and b+8 share an XCD (round-robin dispatch; speed only, never correctness).
+  // XCD-aware tile mapping (speed only, never correctness).  Workgroups are dealt round-robin over the 8 XCDs, so
+  // blocks b and b+8 share an L2.  Bijective remap (cdna_hip_programming.md T1): XCD x owns a contiguous chunk of
+  // the tile list; tiles are ordered M-panel-major, so an XCD walks all N tiles of a panel back to back (A panel
+  // re-read from its own L2) and every XCD gets work even when there are fewer than 8 M panels.
+  const int nwg = nMt * nNt;
   const int b = blockIdx.x;
-  const int xcd = b & 7, q = b >> 3;
-  const int nt = q % nNt;
-  const int mt = (q / nNt) * 8 + xcd;
-  if (mt >= nMt) return;
+  const int xcd = b & 7, idx = b >> 3;
+  const int qq = nwg >> 3, rr = nwg & 7;
+  const int wgid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+  const int mt = wgid / nNt;
+  const int nt = wgid - mt * nNt;
   const int m0 = mt * BM, n0 = nt * BN;
   const int z = blockIdx.y;
   const int kbeg = z * kchunk;
@@ -344,11 +366,10 @@ static int launch_gemm(const typename LA::P& pa, const typename LB::P& pb, const
   constexpr int BM = WM * 64, BN = WN * 64;
   if (M <= 0 || N <= 0 || K <= 0) return CXRK_ERR_ARG;
   const int nMt = ceil_div(M, BM), nNt = ceil_div(N, BN);
-  const int nMt8 = ceil_div(nMt, 8) * 8;
   int kchunk = K;
   if (splitk > 1) { kchunk = ceil_div(ceil_div(K, splitk), BK) * BK; splitk = ceil_div(K, kchunk); }
   else splitk = 1;
-  dim3 grid((unsigned)(nMt8 * nNt), (unsigned)splitk, 1);
+  dim3 grid((unsigned)(nMt * nNt), (unsigned)splitk, 1);
   hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, ep, M, N, K, nMt, nNt, kchunk);
   CXRK_LAUNCH_CHECK();
   return splitk;  // >= 1: number of slabs actually written
