@@ -282,15 +282,58 @@ extern "C" int cxrk_conv_bn_act_bwd_data(const float* dy, const float* w_scaled,
   EpiParams ep{};
   ep.C = dx; ep.ldc = C; ep.R = residual; ep.ldr = C; ep.alpha = 1.f;
   if (relu_src) { ep.aux = relu_src; ep.ldaux = C; ep.auxmode = 1; }
-  int rc;
-  if (C <= 64) {
-    ConvDgradKC<256>::P pa{dy, g, M, K}; ConvFilterMC<64>::P pb{w_scaled, g, C, K};
-    rc = launch_gemm<ConvDgradKC<256>, ConvFilterMC<64>, 4, 1>(pa, pb, ep, M, C, K, 1, stream);
-  } else {
-    ConvDgradKC<128>::P pa{dy, g, M, K}; ConvFilterMC<128>::P pb{w_scaled, g, C, K};
-    rc = launch_gemm<ConvDgradKC<128>, ConvFilterMC<128>, 2, 2>(pa, pb, ep, M, C, K, 1, stream);
+  int rc = 0;
+  if (stride == 1) {
+    if (C <= 64) {
+      ConvDgradKC<256>::P pa{dy, g, M, K}; ConvFilterMC<64>::P pb{w_scaled, g, C, K};
+      rc = launch_gemm<ConvDgradKC<256>, ConvFilterMC<64>, 4, 1>(pa, pb, ep, M, C, K, 1, stream);
+    } else {
+      ConvDgradKC<128>::P pa{dy, g, M, K}; ConvFilterMC<128>::P pb{w_scaled, g, C, K};
+      rc = launch_gemm<ConvDgradKC<128>, ConvFilterMC<128>, 2, 2>(pa, pb, ep, M, C, K, 1, stream);
+    }
+    return rc < 0 ? rc : CXRK_OK;
   }
-  return rc < 0 ? rc : CXRK_OK;
+  // stride 2: one launch per output-parity class, only over the taps that reach it
+  CXRK_CHECK_ARG(R <= 3 && S <= 3);
+  bool zeroed = false;
+  for (int ph = 0; ph < 2; ++ph) {
+    for (int pw = 0; pw < 2; ++pw) {
+      S2Taps t{};
+      for (int r = 0; r < R; ++r) if (((ph + pad - r) & 1) == 0) { t.r[t.nr] = r; t.dr[t.nr] = (ph + pad - r) / 2; ++t.nr; }
+      for (int q = 0; q < S; ++q) if (((pw + pad - q) & 1) == 0) { t.s[t.ns] = q; t.ds[t.ns] = (pw + pad - q) / 2; ++t.ns; }
+      const int Hs = (H - ph + 1) / 2, Ws = (W - pw + 1) / 2;
+      if (Hs <= 0 || Ws <= 0) continue;
+      if (t.nr == 0 || t.ns == 0) {
+        // no tap reaches this class: its pixels are exactly zero.  Only the plain form is supported there.
+        CXRK_CHECK_ARG(residual == nullptr && relu_src == nullptr);
+        if (!zeroed) {
+          if (hipMemsetAsync(dx, 0, (size_t)M * C * sizeof(float), stream) != hipSuccess) return CXRK_ERR_LAUNCH;
+          zeroed = true;
+        }
+      }
+    }
+  }
+  for (int ph = 0; ph < 2; ++ph) {
+    for (int pw = 0; pw < 2; ++pw) {
+      S2Taps t{};
+      for (int r = 0; r < R; ++r) if (((ph + pad - r) & 1) == 0) { t.r[t.nr] = r; t.dr[t.nr] = (ph + pad - r) / 2; ++t.nr; }
+      for (int q = 0; q < S; ++q) if (((pw + pad - q) & 1) == 0) { t.s[t.ns] = q; t.ds[t.ns] = (pw + pad - q) / 2; ++t.ns; }
+      const int Hs = (H - ph + 1) / 2, Ws = (W - pw + 1) / 2;
+      if (Hs <= 0 || Ws <= 0 || t.nr == 0 || t.ns == 0) continue;
+      const int Ms = N * Hs * Ws, Ks = t.nr * t.ns * Ko;
+      EpiParams e2 = ep;
+      e2.rm_on = 1; e2.rm_Hs = Hs; e2.rm_Ws = Ws; e2.rm_H = H; e2.rm_W = W; e2.rm_ph = ph; e2.rm_pw = pw;
+      if (C <= 64) {
+        ConvDgradS2KC<256>::P pa{dy, g, t, Hs, Ws, Ms, Ks}; ConvFilterS2MC<64>::P pb{w_scaled, g, t, C, Ks};
+        rc = launch_gemm<ConvDgradS2KC<256>, ConvFilterS2MC<64>, 4, 1>(pa, pb, e2, Ms, C, Ks, 1, stream);
+      } else {
+        ConvDgradS2KC<128>::P pa{dy, g, t, Hs, Ws, Ms, Ks}; ConvFilterS2MC<128>::P pb{w_scaled, g, t, C, Ks};
+        rc = launch_gemm<ConvDgradS2KC<128>, ConvFilterS2MC<128>, 2, 2>(pa, pb, e2, Ms, C, Ks, 1, stream);
+      }
+      if (rc < 0) return rc;
+    }
+  }
+  return CXRK_OK;
 }
 
 static int wgrad_splitk(int Ko, int Ncols, long Kred) {

@@ -33,6 +33,8 @@ struct EpiParams {
   int act;                       // 0 none, 1 relu, 2 gelu(erf)
   float alpha;                   // scales the accumulator
   long slab_stride;              // split-K: slab z is written at C + z*slab_stride (epilogue must be plain)
+  // optional output-row remap (stride-2 dgrad parity classes): GEMM row (n,a,b) -> pixel (n, 2a+ph, 2b+pw) of [N,H,W]
+  int rm_on, rm_Hs, rm_Ws, rm_H, rm_W, rm_ph, rm_pw;
 };
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -214,6 +216,77 @@ struct ConvFilterMC {
   }
 };
 
+// Stride-2 dgrad, one output-parity class (ph,pw) per launch: only the taps r = (ph+pad) mod 2 (+2) reach pixels
+// (2a+ph, 2b+pw), so the K loop runs over those taps only (no multiply-by-zero work: 9 taps -> 1+2+2+4 over the
+// four classes).  idx = (n,a,b) on the half-resolution grid; k = (ti,ko) with ti indexing the class's tap list.
+struct S2Taps { int nr, ns; int r[2], s[2]; int dr[2], ds[2]; };  // ho = a + dr[tr], wo = b + ds[ts]
+
+template <int TILE>
+struct ConvDgradS2KC {
+  static constexpr int NV = TILE / 32;
+  struct P { const float* dy; ConvGeom g; S2Taps t; int Hs, Ws; int rows; int K; };
+  long nbase[NV]; int pa[NV], pb[NV];
+  const float* dy; int k4, r0, K, Ho, Wo, Ko; S2Taps t;
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    k4 = tid & 7; r0 = tid >> 3; K = p.K; dy = p.dy; Ho = p.g.Ho; Wo = p.g.Wo; Ko = p.g.Ko; t = p.t;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int row = idx0 + r0 + j * 32;
+      if (row < p.rows) {
+        const int b = row % p.Ws; const int q = row / p.Ws; const int a = q % p.Hs; const int n = q / p.Hs;
+        pa[j] = a; pb[j] = b; nbase[j] = (long)n * Ho * Wo * Ko;
+      } else { pa[j] = -(1 << 28); pb[j] = 0; nbase[j] = 0; }
+    }
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
+    const int k = k0 + k4 * 4;
+    const int ti = k / Ko, ko = k - ti * Ko;
+    const int tr = ti / t.ns, ts = ti - tr * t.ns;
+    const int dr = tr == 0 ? t.dr[0] : t.dr[1], ds = ts == 0 ? t.ds[0] : t.ds[1];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int ho = pa[j] + dr, wo = pb[j] + ds;
+      const bool ok = (k < K) && ((unsigned)ho < (unsigned)Ho) && ((unsigned)wo < (unsigned)Wo);
+      v[j] = ok ? *reinterpret_cast<const float4*>(dy + nbase[j] + ((long)ho * Wo + wo) * Ko + ko) : zero4();
+    }
+  }
+  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      float* d = Sm + (k4 * 4) * (TILE + LPAD) + r0 + j * 32;
+      d[0] = v[j].x; d[TILE + LPAD] = v[j].y; d[2 * (TILE + LPAD)] = v[j].z; d[3 * (TILE + LPAD)] = v[j].w;
+    }
+  }
+};
+
+template <int TILE>
+struct ConvFilterS2MC {
+  static constexpr int NV = TILE / 32;
+  static constexpr int VPR = TILE / 4;
+  static constexpr int RPP = NTHREADS / VPR;
+  struct P { const float* w; ConvGeom g; S2Taps t; int cols; int K; };
+  const float* base; int c4, kr0, K, Ko, C, S; long RSC; bool ok; S2Taps t;
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    c4 = tid % VPR; kr0 = tid / VPR; K = p.K; Ko = p.g.Ko; C = p.g.C; S = p.g.S; RSC = (long)p.g.R * p.g.S * p.g.C; t = p.t;
+    ok = idx0 + c4 * 4 < p.cols; base = p.w + idx0 + c4 * 4;
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int k = k0 + kr0 + j * RPP;
+      const int ti = k / Ko, ko = k - ti * Ko;
+      const int tr = ti / t.ns, ts = ti - tr * t.ns;
+      const int tap = (tr == 0 ? t.r[0] : t.r[1]) * S + (ts == 0 ? t.s[0] : t.s[1]);
+      v[j] = (ok && k < K) ? *reinterpret_cast<const float4*>(base + (long)ko * RSC + (long)tap * C) : zero4();
+    }
+  }
+  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      *reinterpret_cast<float4*>(Sm + (kr0 + j * RPP) * (TILE + LPAD) + c4 * 4) = v[j];
+  }
+};
+
 // wgrad B operand: k = (n,ho,wo), idx = (r,s,c) -> x[n][ho*st-pad+r][wo*st-pad+s][c]   (c contiguous)
 // The pixel index k only ever advances by BK between consecutive load() calls, so (n,ho,wo) is carried in
 // registers and stepped with add/compare instead of being re-derived with integer divisions every K-tile.
@@ -344,16 +417,21 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_f32_kernel(typename LA::P pa
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row >= M) continue;
+        const int grow = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (grow >= M) continue;
+        long row = grow;
+        if (ep.rm_on) {
+          const int b_ = grow % ep.rm_Ws; const int q_ = grow / ep.rm_Ws; const int a_ = q_ % ep.rm_Hs; const int n_ = q_ / ep.rm_Hs;
+          row = ((long)n_ * ep.rm_H + 2 * a_ + ep.rm_ph) * ep.rm_W + 2 * b_ + ep.rm_pw;
+        }
         float v = ep.alpha * acc[i][j][e] + bv;
-        if (ep.R) v += ep.R[(long)row * ep.ldr + col];
-        if (ep.C2) ep.C2[(long)row * ep.ldc2 + col] = v;
+        if (ep.R) v += ep.R[row * ep.ldr + col];
+        if (ep.C2) ep.C2[row * ep.ldc2 + col] = v;
         if (ep.act == 1) v = fmaxf(v, 0.f);
         else if (ep.act == 2) v = gelu_erf(v);
-        if (ep.auxmode == 1) v = ep.aux[(long)row * ep.ldaux + col] > 0.f ? v : 0.f;
-        else if (ep.auxmode == 2) v *= gelu_erf_grad(ep.aux[(long)row * ep.ldaux + col]);
-        C[(long)row * ep.ldc + col] = v;
+        if (ep.auxmode == 1) v = ep.aux[row * ep.ldaux + col] > 0.f ? v : 0.f;
+        else if (ep.auxmode == 2) v *= gelu_erf_grad(ep.aux[row * ep.ldaux + col]);
+        C[row * ep.ldc + col] = v;
       }
     }
   }
