@@ -17,6 +17,10 @@
 #pragma once
 #include "cxrk_common.h"
 
+#ifndef CXRK_ABL
+#define CXRK_ABL 0  // ablation switch for scripts/tune_gemm.hip only; the library is always built with 0
+#endif
+
 namespace cxrk {
 
 constexpr int BK = 32;
@@ -48,6 +52,7 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 template <int TILE>
 struct DenseKC {
   static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 1;  // LDS row stride (floats)
   struct P { const float* ptr; long ld; int rows; int K; };
   const float* rp[NV];
   int k4, r0, K;
@@ -67,8 +72,8 @@ struct DenseKC {
   __device__ __forceinline__ void store(float* S, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      float* d = S + (k4 * 4) * (TILE + LPAD) + r0 + j * 32;
-      d[0] = v[j].x; d[TILE + LPAD] = v[j].y; d[2 * (TILE + LPAD)] = v[j].z; d[3 * (TILE + LPAD)] = v[j].w;
+      float* d = S + (k4 * 4) * LD + r0 + j * 32;
+      d[0] = v[j].x; d[LD] = v[j].y; d[2 * LD] = v[j].z; d[3 * LD] = v[j].w;
     }
   }
 };
@@ -77,6 +82,7 @@ struct DenseKC {
 template <int TILE>
 struct DenseMC {
   static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 4;  // LDS row stride (floats)
   static constexpr int VPR = TILE / 4;          // float4 per k-row
   static constexpr int RPP = NTHREADS / VPR;    // k-rows per pass
   struct P { const float* ptr; long ld; int cols; int K; };
@@ -97,7 +103,7 @@ struct DenseMC {
   __device__ __forceinline__ void store(float* S, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j)
-      *reinterpret_cast<float4*>(S + (kr0 + j * RPP) * (TILE + LPAD) + c4 * 4) = v[j];
+      *reinterpret_cast<float4*>(S + (kr0 + j * RPP) * LD + c4 * 4) = v[j];
   }
 };
 
@@ -112,6 +118,7 @@ struct ConvGeom {
 template <int TILE>
 struct ConvIm2colKC {
   static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 1;  // LDS row stride (floats)
   struct P { const float* x; ConvGeom g; int rows; int K; };
   long off[NV]; int hi0[NV], wi0[NV];
   const float* x; int k4, r0, K, H, W, C, S;
@@ -142,8 +149,8 @@ struct ConvIm2colKC {
   __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      float* d = Sm + (k4 * 4) * (TILE + LPAD) + r0 + j * 32;
-      d[0] = v[j].x; d[TILE + LPAD] = v[j].y; d[2 * (TILE + LPAD)] = v[j].z; d[3 * (TILE + LPAD)] = v[j].w;
+      float* d = Sm + (k4 * 4) * LD + r0 + j * 32;
+      d[0] = v[j].x; d[LD] = v[j].y; d[2 * LD] = v[j].z; d[3 * LD] = v[j].w;
     }
   }
 };
@@ -152,6 +159,7 @@ struct ConvIm2colKC {
 template <int TILE>
 struct ConvDgradKC {
   static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 1;  // LDS row stride (floats)
   struct P { const float* dy; ConvGeom g; int rows; int K; };
   long nbase[NV]; int hp[NV], wp[NV];
   const float* dy; int k4, r0, K, Ho, Wo, Ko, S, st;
@@ -183,8 +191,8 @@ struct ConvDgradKC {
   __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      float* d = Sm + (k4 * 4) * (TILE + LPAD) + r0 + j * 32;
-      d[0] = v[j].x; d[TILE + LPAD] = v[j].y; d[2 * (TILE + LPAD)] = v[j].z; d[3 * (TILE + LPAD)] = v[j].w;
+      float* d = Sm + (k4 * 4) * LD + r0 + j * 32;
+      d[0] = v[j].x; d[LD] = v[j].y; d[2 * LD] = v[j].z; d[3 * LD] = v[j].w;
     }
   }
 };
@@ -193,6 +201,7 @@ struct ConvDgradKC {
 template <int TILE>
 struct ConvFilterMC {
   static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 4;  // LDS row stride (floats)
   static constexpr int VPR = TILE / 4;
   static constexpr int RPP = NTHREADS / VPR;
   struct P { const float* w; ConvGeom g; int cols; int K; };
@@ -212,7 +221,7 @@ struct ConvFilterMC {
   __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j)
-      *reinterpret_cast<float4*>(Sm + (kr0 + j * RPP) * (TILE + LPAD) + c4 * 4) = v[j];
+      *reinterpret_cast<float4*>(Sm + (kr0 + j * RPP) * LD + c4 * 4) = v[j];
   }
 };
 
@@ -224,6 +233,7 @@ struct S2Taps { int nr, ns; int r[2], s[2]; int dr[2], ds[2]; };  // ho = a + dr
 template <int TILE>
 struct ConvDgradS2KC {
   static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 1;  // LDS row stride (floats)
   struct P { const float* dy; ConvGeom g; S2Taps t; int Hs, Ws; int rows; int K; };
   long nbase[NV]; int pa[NV], pb[NV];
   const float* dy; int k4, r0, K, Ho, Wo, Ko; S2Taps t;
@@ -253,8 +263,8 @@ struct ConvDgradS2KC {
   __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      float* d = Sm + (k4 * 4) * (TILE + LPAD) + r0 + j * 32;
-      d[0] = v[j].x; d[TILE + LPAD] = v[j].y; d[2 * (TILE + LPAD)] = v[j].z; d[3 * (TILE + LPAD)] = v[j].w;
+      float* d = Sm + (k4 * 4) * LD + r0 + j * 32;
+      d[0] = v[j].x; d[LD] = v[j].y; d[2 * LD] = v[j].z; d[3 * LD] = v[j].w;
     }
   }
 };
@@ -262,6 +272,7 @@ struct ConvDgradS2KC {
 template <int TILE>
 struct ConvFilterS2MC {
   static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 4;  // LDS row stride (floats)
   static constexpr int VPR = TILE / 4;
   static constexpr int RPP = NTHREADS / VPR;
   struct P { const float* w; ConvGeom g; S2Taps t; int cols; int K; };
@@ -283,7 +294,7 @@ struct ConvFilterS2MC {
   __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j)
-      *reinterpret_cast<float4*>(Sm + (kr0 + j * RPP) * (TILE + LPAD) + c4 * 4) = v[j];
+      *reinterpret_cast<float4*>(Sm + (kr0 + j * RPP) * LD + c4 * 4) = v[j];
   }
 };
 
@@ -293,6 +304,7 @@ struct ConvFilterS2MC {
 template <int TILE>
 struct ConvIm2colMC {
   static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 4;  // LDS row stride (floats)
   static constexpr int VPR = TILE / 4;
   static constexpr int RPP = NTHREADS / VPR;
   struct P { const float* x; ConvGeom g; int cols; int K; };
@@ -333,19 +345,35 @@ struct ConvIm2colMC {
   __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j)
-      *reinterpret_cast<float4*>(Sm + (kr0 + j * RPP) * (TILE + LPAD) + c4 * 4) = v[j];
+      *reinterpret_cast<float4*>(Sm + (kr0 + j * RPP) * LD + c4 * 4) = v[j];
   }
 };
 
 // ---------------------------------------------------------------------------------------------------------------
 // Kernel
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef CXRK_OCC
+#define CXRK_OCC 3
+#endif
 template <class LA, class LB, int WM, int WN>
-__global__ __launch_bounds__(NTHREADS, 3) void gemm_f32_kernel(typename LA::P pa, typename LB::P pb, EpiParams ep,
+__global__ __launch_bounds__(NTHREADS, CXRK_OCC) void gemm_f32_kernel(typename LA::P pa, typename LB::P pb, EpiParams ep,
                                                             int M, int N, int K, int nMt, int nNt, int kchunk) {
   constexpr int BM = WM * 64, BN = WN * 64;
-  __shared__ __attribute__((aligned(16))) float As[BK * (BM + LPAD)];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * (BN + LPAD)];
+  constexpr int LDA = LA::LD, LDB = LB::LD;
+  constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
+  // ONE LDS buffer per operand (33-41 KB, 3 blocks = 3 waves/SIMD per CU) and two barriers per K-tile.  Measured on
+  // 32768x3072x768 (scripts/tune_gemm.hip): 113 TFLOP/s, against 99 for two buffers at 2 blocks/CU (66 KB) and 107 for
+  // one buffer at 4 waves/SIMD (register pressure): co-resident blocks run in lockstep, so a third block per CU
+  // hides more of the staging / epilogue phases than removing a barrier does.  NBUF = 2 is kept as a tuning option.
+  // All LDS lives in ONE array (cdna_hip_programming.md: a second __shared__ object can de-pipeline the loop).
+#ifdef CXRK_NBUF
+  constexpr int NBUF = CXRK_NBUF;  // tuning override (scripts/tune_gemm.hip)
+#else
+  constexpr int NBUF = 1;
+#endif
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * (ASZ + BSZ)];
+  float* const As0 = smem;
+  float* const Bs0 = smem + NBUF * ASZ;
 
   // XCD-aware tile mapping (speed only, never correctness).  Workgroups are dealt round-robin over the 8 XCDs, so
   // blocks b and b+8 share an L2.  Bijective remap (cdna_hip_programming.md T1): XCD x owns a contiguous chunk of
@@ -381,29 +409,48 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_f32_kernel(typename LA::P pa
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   float4 ra[LA::NV], rb[LB::NV];
-  if (kbeg < kend) { la.load(kbeg, ra); lb.load(kbeg, rb); }
+  if (kbeg < kend) {
+    la.load(kbeg, ra); lb.load(kbeg, rb);
+    la.store(As0, ra); lb.store(Bs0, rb);
+  }
+  __syncthreads();
+  if (kbeg + BK < kend) { la.load(kbeg + BK, ra); lb.load(kbeg + BK, rb); }
 
-  const float* Ap = As + wm * 64 + r;
-  const float* Bp = Bs + wn * 64 + r;
-
+  // Main loop.  MFMAs are asynchronous to the issuing wave (64 cycles each), so the staging of the NEXT tiles is
+  // interleaved between them instead of being appended: with two LDS buffers the registers holding tile t+1 are
+  // written to the other buffer a quarter of the way through tile t, and the global loads of tile t+2 are issued at
+  // the half-way point; only one barrier per K-tile remains.  (Single-buffer tiles stage after the MFMA block.)
+  int cur = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    la.store(As, ra);
-    lb.store(Bs, rb);
-    __syncthreads();
-    if (k0 + BK < kend) { la.load(k0 + BK, ra); lb.load(k0 + BK, rb); }
+    const float* Ap = As0 + cur * ASZ + wm * 64 + r + h * LDA;
+    const float* Bp = Bs0 + cur * BSZ + wn * 64 + r + h * LDB;
+    const bool has1 = k0 + BK < kend, has2 = k0 + 2 * BK < kend;
+    float a0 = Ap[0], a1 = Ap[32], b0 = Bp[0], b1 = Bp[32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      const int krow = 2 * kk + h;
-      const float a0 = Ap[krow * (BM + LPAD)];
-      const float a1 = Ap[krow * (BM + LPAD) + 32];
-      const float b0 = Bp[krow * (BN + LPAD)];
-      const float b1 = Bp[krow * (BN + LPAD) + 32];
+      float a0n = 0.f, a1n = 0.f, b0n = 0.f, b1n = 0.f;
+      if (CXRK_ABL == 4 || CXRK_ABL == 6) { a0n = a0 + 1.f; a1n = a1; b0n = b0; b1n = b1; } else
+      if (kk + 1 < BK / 2) {
+        a0n = Ap[(2 * kk + 2) * LDA]; a1n = Ap[(2 * kk + 2) * LDA + 32];
+        b0n = Bp[(2 * kk + 2) * LDB]; b1n = Bp[(2 * kk + 2) * LDB + 32];
+      }
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
+      if (NBUF == 2 && CXRK_ABL != 4 && CXRK_ABL != 6) {
+        if (kk == 3 && has1 && CXRK_ABL != 2) { la.store(As0 + (cur ^ 1) * ASZ, ra); lb.store(Bs0 + (cur ^ 1) * BSZ, rb); }
+        if (kk == 7 && has2 && CXRK_ABL != 1) { la.load(k0 + 2 * BK, ra); lb.load(k0 + 2 * BK, rb); }
+      }
     }
-    __syncthreads();
+    if (NBUF == 1 && CXRK_ABL != 4 && CXRK_ABL != 6) {
+      if (CXRK_ABL != 3) __syncthreads();  // single buffer: everyone must be done reading before it is overwritten
+      if (has1 && CXRK_ABL != 2) { la.store(As0, ra); lb.store(Bs0, rb); }
+    }
+    if (CXRK_ABL != 3 && CXRK_ABL != 4 && CXRK_ABL != 6) __syncthreads();
+    if (NBUF == 1 && has2 && CXRK_ABL != 1 && CXRK_ABL != 4 && CXRK_ABL != 6) { la.load(k0 + 2 * BK, ra); lb.load(k0 + 2 * BK, rb); }
+    if (NBUF == 2) cur ^= 1;
   }
 
   // Epilogue.  C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -425,6 +472,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void gemm_f32_kernel(typename LA::P pa
           row = ((long)n_ * ep.rm_H + 2 * a_ + ep.rm_ph) * ep.rm_W + 2 * b_ + ep.rm_pw;
         }
         float v = ep.alpha * acc[i][j][e] + bv;
+        if ((CXRK_ABL == 5 || CXRK_ABL == 6) && v != 12345.678f) continue;  // ablation: drop the epilogue traffic
         if (ep.R) v += ep.R[row * ep.ldr + col];
         if (ep.C2) ep.C2[row * ep.ldc2 + col] = v;
         if (ep.act == 1) v = fmaxf(v, 0.f);
