@@ -39,6 +39,7 @@ struct EpiParams {
   long slab_stride;              // split-K: slab z is written at C + z*slab_stride (epilogue must be plain)
   // optional output-row remap (stride-2 dgrad parity classes): GEMM row (n,a,b) -> pixel (n, 2a+ph, 2b+pw) of [N,H,W]
   int rm_on, rm_Hs, rm_Ws, rm_H, rm_W, rm_ph, rm_pw;
+  int vec;  // set by launch_gemm: every pointer / leading dimension allows 16-byte row accesses
 };
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -453,35 +454,75 @@ __global__ __launch_bounds__(NTHREADS, CXRK_OCC) void gemm_f32_kernel(typename L
     if (NBUF == 2) cur ^= 1;
   }
 
-  // Epilogue.  C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  // Epilogue.  C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), i.e. a
+  // lane owns ONE column — stored straight from the accumulators that is 64 dword stores per lane in 128-B pieces.
+  // Instead each wave transposes its 64x64 sub-tile through the (now free) operand LDS in two 32-row passes and
+  // leaves with 16 B per lane: 16 float4 stores per lane, 256 contiguous bytes per row, and the residual / mask /
+  // GELU' side inputs are read the same way.  This is what the HBM-bound shapes (1x1 convolutions with K = 64) pay for.
+  static_assert(BK * (LDA + LDB) >= 4 * 32 * 64, "operand LDS too small to stage the epilogue");
+  __syncthreads();  // every wave is done reading operand tiles
+  float* const st = smem + wave * (32 * 64);
   float* C = ep.C + (long)z * ep.slab_stride;
+  const int c4 = lane & 15, rq = lane >> 4;
+  const int col = n0 + wn * 64 + c4 * 4;
+  float4 bv = zero4();
+  if (ep.bias && col < N) {
+    if (ep.vec) bv = *reinterpret_cast<const float4*>(ep.bias + col);
+    else { bv.x = ep.bias[col]; if (col + 1 < N) bv.y = ep.bias[col + 1]; if (col + 2 < N) bv.z = ep.bias[col + 2]; if (col + 3 < N) bv.w = ep.bias[col + 3]; }
+  }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + r;
-    if (col >= N) continue;
-    const float bv = ep.bias ? ep.bias[col] : 0.f;
+  for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int grow = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (grow >= M) continue;
-        long row = grow;
-        if (ep.rm_on) {
-          const int b_ = grow % ep.rm_Ws; const int q_ = grow / ep.rm_Ws; const int a_ = q_ % ep.rm_Hs; const int n_ = q_ / ep.rm_Hs;
-          row = ((long)n_ * ep.rm_H + 2 * a_ + ep.rm_ph) * ep.rm_W + 2 * b_ + ep.rm_pw;
+      for (int e = 0; e < 16; ++e) st[((e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[i][j][e];
+    __builtin_amdgcn_wave_barrier();  // LDS serves one wave's accesses in issue order; keep the compiler from reordering
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int rl = t * 4 + rq;
+      const int grow = m0 + wm * 64 + i * 32 + rl;
+      float4 v4 = *reinterpret_cast<const float4*>(st + rl * 64 + c4 * 4);
+      if (grow >= M || col >= N) continue;
+      long row = grow;
+      if (ep.rm_on) {
+        const int b_ = grow % ep.rm_Ws; const int q_ = grow / ep.rm_Ws; const int a_ = q_ % ep.rm_Hs; const int n_ = q_ / ep.rm_Hs;
+        row = ((long)n_ * ep.rm_H + 2 * a_ + ep.rm_ph) * ep.rm_W + 2 * b_ + ep.rm_pw;
+      }
+      float v[4] = {ep.alpha * v4.x + bv.x, ep.alpha * v4.y + bv.y, ep.alpha * v4.z + bv.z, ep.alpha * v4.w + bv.w};
+      if ((CXRK_ABL == 5 || CXRK_ABL == 6) && v[0] != 12345.678f) continue;  // ablation: drop the epilogue traffic
+      if (ep.vec) {
+        if (ep.R) { const float4 q = *reinterpret_cast<const float4*>(ep.R + row * ep.ldr + col); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
+        if (ep.C2) *reinterpret_cast<float4*>(ep.C2 + row * ep.ldc2 + col) = make_float4(v[0], v[1], v[2], v[3]);
+        if (ep.act == 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        } else if (ep.act == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
         }
-        float v = ep.alpha * acc[i][j][e] + bv;
-        if ((CXRK_ABL == 5 || CXRK_ABL == 6) && v != 12345.678f) continue;  // ablation: drop the epilogue traffic
-        if (ep.R) v += ep.R[row * ep.ldr + col];
-        if (ep.C2) ep.C2[row * ep.ldc2 + col] = v;
-        if (ep.act == 1) v = fmaxf(v, 0.f);
-        else if (ep.act == 2) v = gelu_erf(v);
-        if (ep.auxmode == 1) v = ep.aux[row * ep.ldaux + col] > 0.f ? v : 0.f;
-        else if (ep.auxmode == 2) v *= gelu_erf_grad(ep.aux[row * ep.ldaux + col]);
-        C[row * ep.ldc + col] = v;
+        if (ep.auxmode) {
+          const float4 q4 = *reinterpret_cast<const float4*>(ep.aux + row * ep.ldaux + col);
+          const float ax[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = ep.auxmode == 1 ? (ax[q] > 0.f ? v[q] : 0.f) : v[q] * gelu_erf_grad(ax[q]);
+        }
+        *reinterpret_cast<float4*>(C + row * ep.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (col + q >= N) break;
+          float x = v[q];
+          if (ep.R) x += ep.R[row * ep.ldr + col + q];
+          if (ep.C2) ep.C2[row * ep.ldc2 + col + q] = x;
+          if (ep.act == 1) x = fmaxf(x, 0.f);
+          else if (ep.act == 2) x = gelu_erf(x);
+          if (ep.auxmode == 1) x = ep.aux[row * ep.ldaux + col + q] > 0.f ? x : 0.f;
+          else if (ep.auxmode == 2) x *= gelu_erf_grad(ep.aux[row * ep.ldaux + col + q]);
+          C[row * ep.ldc + col + q] = x;
+        }
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -496,7 +537,11 @@ static int launch_gemm(const typename LA::P& pa, const typename LB::P& pb, const
   if (splitk > 1) { kchunk = ceil_div(ceil_div(K, splitk), BK) * BK; splitk = ceil_div(K, kchunk); }
   else splitk = 1;
   dim3 grid((unsigned)(nMt * nNt), (unsigned)splitk, 1);
-  hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, ep, M, N, K, nMt, nNt, kchunk);
+  EpiParams e = ep;
+  auto ok16 = [](const void* p_, long ld) { return p_ == nullptr || (aligned16(p_) && (ld % 4) == 0); };
+  e.vec = (N % 4 == 0) && ok16(e.C, e.ldc) && ((e.slab_stride % 4) == 0) && ok16(e.R, e.ldr) && ok16(e.aux, e.ldaux) &&
+          ok16(e.C2, e.ldc2) && (e.bias == nullptr || aligned16(e.bias));
+  hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
   CXRK_LAUNCH_CHECK();
   return splitk;  // >= 1: number of slabs actually written
 }
