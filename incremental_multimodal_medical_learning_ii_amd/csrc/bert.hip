@@ -287,8 +287,8 @@ extern "C" int cxrk_residual_ln_fwd(const float* x, const float* res, const floa
 }
 
 static int ln_bwd_blocks(long rows) {
-  long nb = (rows + 31) / 32;
-  if (nb > 1024) nb = 1024;
+  long nb = (rows + 63) / 64;
+  if (nb > 256) nb = 256;   // one block per CU; the final reduction walks nb partials per column
   if (nb < 1) nb = 1;
   return (int)nb;
 }

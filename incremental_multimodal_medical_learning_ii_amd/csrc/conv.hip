@@ -35,37 +35,56 @@ __global__ void bn_fold_kernel(const float* __restrict__ w, const float* __restr
   }
 }
 
-// One block per output channel: dW[ko] = scale[ko] * sum_z slab_z[ko], dgamma, dbeta.
-//   dbeta[ko] = sumdy[ko];  dgamma[ko] = sum dy*xhat = sumdyy[ko] / gamma[ko]  with sumdyy = sum dy*(y_bn - beta)
-//   (fallback: rstd*(<w[ko], dWraw[ko]> - rmean*sumdy), exact in exact arithmetic since z is linear in w).
-__global__ void wgrad_reduce_bn_kernel(const float* __restrict__ slabs, int nslab, long slab_stride, int taps, int C, int Cpad,
-                                       const float* __restrict__ w, const float* __restrict__ scale,
-                                       const float* __restrict__ rstd, const float* __restrict__ rmean,
-                                       const float* __restrict__ sumdy, const float* __restrict__ gamma,
-                                       const float* __restrict__ sumdyy, float* __restrict__ dw,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+// dW[ko][tap][c] = scale[ko] * sum_z slab_z[ko][tap][c<Cpad]  (channel un-padding), one block per (ko, 1024-element
+// part); dbeta[ko] = sumdy[ko];  dgamma[ko] = sum dy*xhat = sumdyy[ko] / gamma[ko]  with sumdyy = sum dy*(y_bn - beta).
+// Only when gamma == 0 (or no y_bn sums were supplied) the algebraically equal but badly conditioned form
+// rstd*(<w[ko], dWraw[ko]> - rmean*sumdy) is evaluated (by the part-0 block, serially: it is the rare path).
+__global__ __launch_bounds__(256) void wgrad_reduce_bn_kernel(const float* __restrict__ slabs, int nslab, long slab_stride,
+                                                              int taps, int C, int Cpad, const float* __restrict__ w,
+                                                              const float* __restrict__ scale, const float* __restrict__ rstd,
+                                                              const float* __restrict__ rmean, const float* __restrict__ sumdy,
+                                                              const float* __restrict__ gamma, const float* __restrict__ sumdyy,
+                                                              float* __restrict__ dw, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate) {
   __shared__ float sh[16];
   const int ko = blockIdx.x;
   const int n = taps * Cpad;
   const float sc = scale ? scale[ko] : 1.f;
-  float dot = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < nslab; ++z) s += slabs[(long)z * slab_stride + (long)ko * n + i];
-    const int tap = i / Cpad, c = i - tap * Cpad;
-    if (c < C) {
-      const long o = ((long)ko * taps + tap) * C + c;
-      dot += w[o] * s;
-      dw[o] = accumulate ? dw[o] + sc * s : sc * s;
+  const int i4 = (blockIdx.y * 256 + threadIdx.x) * 4;
+  if (i4 < n) {  // Cpad % 4 == 0 -> the 4 elements share a tap
+    const float* src = slabs + (long)ko * n + i4;
+    float4 s = *reinterpret_cast<const float4*>(src);
+    for (int z = 1; z < nslab; ++z) {
+      const float4 t = *reinterpret_cast<const float4*>(src + (long)z * slab_stride);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    const int tap = i4 / Cpad, c = i4 - tap * Cpad;
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (c + q < C) {
+        const long o = ((long)ko * taps + tap) * C + c + q;
+        dw[o] = accumulate ? dw[o] + sc * sv[q] : sc * sv[q];
+      }
     }
   }
-  if (dgamma) {
-    dot = block_sum(dot, sh);
+  if (dgamma && blockIdx.y == 0) {
+    float g;
+    const bool direct = gamma && sumdyy && gamma[ko] != 0.f;
+    if (direct) {
+      g = sumdyy[ko] / gamma[ko];
+    } else {
+      float dot = 0.f;
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < nslab; ++z) s += slabs[(long)z * slab_stride + (long)ko * n + i];
+        const int tap = i / Cpad, c = i - tap * Cpad;
+        if (c < C) dot += w[((long)ko * taps + tap) * C + c] * s;
+      }
+      dot = block_sum(dot, sh);
+      g = rstd[ko] * (dot - rmean[ko] * sumdy[ko]);
+    }
     if (threadIdx.x == 0) {
-      // preferred: sum dy*(y_bn - beta) / gamma (well conditioned); fallback when gamma == 0 or no y_bn is available:
-      // rstd*(<w,wgrad> - mean*sumdy), which cancels badly when the conv input has a large DC component.
-      const float g = (gamma && sumdyy && gamma[ko] != 0.f) ? sumdyy[ko] / gamma[ko]
-                                                            : rstd[ko] * (dot - rmean[ko] * sumdy[ko]);
       dgamma[ko] = accumulate ? dgamma[ko] + g : g;
       dbeta[ko] = accumulate ? dbeta[ko] + sumdy[ko] : sumdy[ko];
     }
@@ -201,20 +220,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_partial_kernel(const float*
     part[((long)blockIdx.y * 2 + 1) * C + c] = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
   }
 }
-__global__ void bn_bwd_reduce_final_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ sumdy,
-                                           float* __restrict__ sumdyy) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+// stage 2: block = 64 columns x 4 part-lanes
+__global__ __launch_bounds__(256) void bn_bwd_reduce_final_kernel(const float* __restrict__ part, int nparts, int C,
+                                                                  float* __restrict__ sumdy, float* __restrict__ sumdyy) {
+  __shared__ float sh[2][4][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float a = 0.f, b = 0.f;
-  for (int p = 0; p < nparts; ++p) { a += part[((long)p * 2) * C + c]; b += part[((long)p * 2 + 1) * C + c]; }
-  sumdy[c] = a; sumdyy[c] = b;
+  if (c < C)
+    for (int p = pl; p < nparts; p += 4) { a += part[((long)p * 2) * C + c]; b += part[((long)p * 2 + 1) * C + c]; }
+  sh[0][pl][cl] = a; sh[1][pl][cl] = b;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    sumdy[c] = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
+    sumdyy[c] = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
+  }
 }
 
 }  // namespace
 
 static int bn_reduce_parts(long rows, int C) {
   const int cb = ceil_div(C, 64);
-  long np = 2048 / cb; if (np < 1) np = 1;
+  long np = 1024 / cb; if (np < 16) np = 16; if (np > 512) np = 512;
   const long maxp = (rows + 63) / 64; if (np > maxp) np = maxp;
   if (np < 1) np = 1;
   return (int)np;
@@ -231,7 +258,7 @@ extern "C" int cxrk_bn_bwd_reduce(const float* dy, const float* y, const float* 
   hipLaunchKernelGGL(bn_bwd_reduce_partial_kernel, dim3(ceil_div(C, 64), np), dim3(256), 0, stream, dy, y, sub, beta, rows, C,
                      rows_per, ws);
   CXRK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, ws, np, C, sumdy, sumdyy);
+  hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, stream, ws, np, C, sumdy, sumdyy);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
 }
@@ -379,7 +406,7 @@ extern "C" int cxrk_conv_bn_act_bwd_params(const float* x, const float* dy, cons
     rc = launch_gemm<DenseMC<128>, ConvIm2colMC<128>, 2, 2>(pa, pb, ep, Ko, Nc, Kred, sk, stream);
   }
   if (rc < 0) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_bn_kernel, dim3(Ko), dim3(256), 0, stream, ws, rc, (long)Ko * Nc, R * S, C, Cpad, w,
+  hipLaunchKernelGGL(wgrad_reduce_bn_kernel, dim3(Ko, ceil_div(Nc, 1024)), dim3(256), 0, stream, ws, rc, (long)Ko * Nc, R * S, C, Cpad, w,
                      scale, rstd, rmean, sumdy, gamma, sumdyy, dw, dgamma, dbeta, accumulate);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
