@@ -200,8 +200,14 @@ def main():
                 achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 tot_ms = sum(v["ms"] for v in summ.values())
                 tot_fl = sum(v["flops"] for v in summ.values())
+                traffic = None
+                try:  # HBM bytes per launch of this kernel from the committed PMC pass of the same command
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                    traffic = pmc["kernels"].get(key.replace("gemm_f32_kernel<", "gemm_f32_kernel<").replace(",2,2>", ",2,2>"), {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
                 out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "kernel": key,
+                                   "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "kernel": key,
                                    "launches_per_step": d["launches"] / args.steps,
                                    "avg_launch_ms": d["ms"] / d["launches"],
                                    "gflop_per_launch": d["flops"] / d["launches"] / 1e9,
