@@ -69,6 +69,14 @@ int cxrk_conv_bn_act_fwd(const float* x, const float* w_scaled, const float* shi
 int cxrk_conv_bn_act_bwd_data(const float* dy, const float* w_scaled, const float* residual, const float* relu_src,
                               float* dx, int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad,
                               hipStream_t stream);
+/* bwd_data + the BN channel sums (cxrk_bn_bwd_reduce's outputs, plus the downsample unit's) of the unit that produced
+ * relu_src, fused into the data-gradient epilogue: sums[0]=sum dx, sums[1]=sum dx*(relu_src-bn_sub-bn_beta),
+ * sums[2]=sum dx*(bn_sub-bn_beta2).  Not for 1x1 stride-2 filters. */
+size_t cxrk_conv_bwd_data_bnsum_ws_bytes(int N, int H, int W, int C, int stride);
+int cxrk_conv_bn_act_bwd_data_bnsum(const float* dy, const float* w_scaled, const float* residual, const float* relu_src,
+                                    float* dx, int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad,
+                                    const float* bn_sub, const float* bn_beta, const float* bn_beta2, float* sums,
+                                    float* ws, size_t ws_bytes, hipStream_t stream);
 size_t cxrk_conv_wgrad_ws_bytes(int N, int H, int W, int Cpad, int Ko, int R, int S, int stride, int pad);
 size_t cxrk_bn_bwd_reduce_ws_bytes(long rows, int C);
 int cxrk_bn_bwd_reduce(const float* dy, const float* y, const float* sub, const float* beta, long rows, int C,

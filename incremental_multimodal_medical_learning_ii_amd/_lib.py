@@ -24,6 +24,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_bn_fold": (I, [P, P, P, P, P, F, I, I, I, I, P, P, P, P, P]),
     "cxrk_conv_bn_act_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "cxrk_conv_bn_act_bwd_data": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "cxrk_conv_bwd_data_bnsum_ws_bytes": (Z, [I, I, I, I, I]),
+    "cxrk_conv_bn_act_bwd_data_bnsum": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P, P, Z, P]),
     "cxrk_conv_wgrad_ws_bytes": (Z, [I, I, I, I, I, I, I, I, I]),
     "cxrk_bn_bwd_reduce_ws_bytes": (Z, [L, I]),
     "cxrk_bn_bwd_reduce": (I, [P, P, P, P, L, I, P, P, P, Z, P]),

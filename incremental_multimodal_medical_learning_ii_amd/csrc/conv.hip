@@ -237,6 +237,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_final_kernel(const float* _
   }
 }
 
+// sums[k][c] = sum_p part[p][k][c], k = 0..2; block = 64 columns x 16 part-lanes
+__global__ __launch_bounds__(1024) void bn_part_final_kernel(const float* __restrict__ part, int nparts, int C,
+                                                             float* __restrict__ sums) {
+  __shared__ float sh[16][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, k = blockIdx.y;
+  float a = 0.f;
+  if (c < C)
+    for (int p = pl; p < nparts; p += 16) a += part[((long)p * 3 + k) * C + c];
+  sh[pl][cl] = a;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sh[i][cl];
+    sums[(long)k * C + c] = t;
+  }
+}
+
 }  // namespace
 
 static int bn_reduce_parts(long rows, int C) {
@@ -297,9 +316,20 @@ extern "C" int cxrk_conv_bn_act_fwd(const float* x, const float* w_scaled, const
 }
 
 // dx[n][hi][wi][c] = mask( sum_{r,s,ko} dy[n][(hi+pad-r)/st][(wi+pad-s)/st][ko] * w_scaled[ko][r][s][c] + residual )
-extern "C" int cxrk_conv_bn_act_bwd_data(const float* dy, const float* w_scaled, const float* residual,
-                                         const float* relu_src, float* dx, int N, int H, int W, int C, int Ko, int R, int S,
-                                         int stride, int pad, hipStream_t stream) {
+static int dgrad_tiles(int rows, int C) { return ceil_div(rows, C <= 64 ? 256 : 128) * (C <= 64 ? 4 : 2); }
+
+// number of per-wave partial rows the fused BN reduction of a data-gradient launch produces (all parity classes)
+static long dgrad_bn_parts(int N, int H, int W, int C, int stride) {
+  if (stride == 1) return dgrad_tiles(N * H * W, C);
+  long t = 0;
+  for (int ph = 0; ph < 2; ++ph)
+    for (int pw = 0; pw < 2; ++pw) { const int Hs = (H - ph + 1) / 2, Ws = (W - pw + 1) / 2; if (Hs > 0 && Ws > 0) t += dgrad_tiles(N * Hs * Ws, C); }
+  return t;
+}
+
+static int conv_bwd_data_impl(const float* dy, const float* w_scaled, const float* residual, const float* relu_src, float* dx,
+                              int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad, float* bn_part,
+                              const float* bn_sub, const float* bn_beta, const float* bn_beta2, hipStream_t stream) {
   CXRK_CHECK_ARG(dy && w_scaled && dx && N > 0 && C % 4 == 0 && Ko % 4 == 0 && aligned16(dy) && aligned16(w_scaled));
   CXRK_CHECK_ARG(stride == 1 || stride == 2);
   const ConvGeom g = make_geom(N, H, W, C, Ko, R, S, stride, pad);
@@ -309,6 +339,7 @@ extern "C" int cxrk_conv_bn_act_bwd_data(const float* dy, const float* w_scaled,
   EpiParams ep{};
   ep.C = dx; ep.ldc = C; ep.R = residual; ep.ldr = C; ep.alpha = 1.f;
   if (relu_src) { ep.aux = relu_src; ep.ldaux = C; ep.auxmode = 1; }
+  ep.bn_part = bn_part; ep.bn_sub = bn_sub; ep.bn_ldsub = C; ep.bn_beta = bn_beta; ep.bn_beta2 = bn_beta2;
   int rc = 0;
   if (stride == 1) {
     if (C <= 64) {
@@ -322,6 +353,7 @@ extern "C" int cxrk_conv_bn_act_bwd_data(const float* dy, const float* w_scaled,
   }
   // stride 2: one launch per output-parity class, only over the taps that reach it
   CXRK_CHECK_ARG(R <= 3 && S <= 3);
+  long part_off = 0;
   bool zeroed = false;
   for (int ph = 0; ph < 2; ++ph) {
     for (int pw = 0; pw < 2; ++pw) {
@@ -349,6 +381,7 @@ extern "C" int cxrk_conv_bn_act_bwd_data(const float* dy, const float* w_scaled,
       if (Hs <= 0 || Ws <= 0 || t.nr == 0 || t.ns == 0) continue;
       const int Ms = N * Hs * Ws, Ks = t.nr * t.ns * Ko;
       EpiParams e2 = ep;
+      if (bn_part) { e2.bn_part = bn_part + part_off * 3 * C; part_off += dgrad_tiles(Ms, C); }
       e2.rm_on = 1; e2.rm_Hs = Hs; e2.rm_Ws = Ws; e2.rm_H = H; e2.rm_W = W; e2.rm_ph = ph; e2.rm_pw = pw;
       if (C <= 64) {
         ConvDgradS2KC<256>::P pa{dy, g, t, Hs, Ws, Ms, Ks}; ConvFilterS2MC<64>::P pb{w_scaled, g, t, C, Ks};
@@ -360,6 +393,37 @@ extern "C" int cxrk_conv_bn_act_bwd_data(const float* dy, const float* w_scaled,
       if (rc < 0) return rc;
     }
   }
+  return CXRK_OK;
+}
+
+extern "C" int cxrk_conv_bn_act_bwd_data(const float* dy, const float* w_scaled, const float* residual,
+                                         const float* relu_src, float* dx, int N, int H, int W, int C, int Ko, int R, int S,
+                                         int stride, int pad, hipStream_t stream) {
+  return conv_bwd_data_impl(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R, S, stride, pad, nullptr, nullptr, nullptr,
+                            nullptr, stream);
+}
+
+extern "C" size_t cxrk_conv_bwd_data_bnsum_ws_bytes(int N, int H, int W, int C, int stride) {
+  return (size_t)dgrad_bn_parts(N, H, W, C, stride) * 3 * C * sizeof(float);
+}
+
+// Data gradient + the BatchNorm-backward channel sums of the unit that PRODUCED relu_src, in one pass:
+//   sums[0][c] = sum dx,  sums[1][c] = sum dx*(relu_src - bn_sub - bn_beta[c]),  sums[2][c] = sum dx*(bn_sub - bn_beta2[c])
+// (dx = the masked gradient this call writes = that unit's dy; relu_src - bn_sub = its BN output where dx != 0).
+extern "C" int cxrk_conv_bn_act_bwd_data_bnsum(const float* dy, const float* w_scaled, const float* residual,
+                                               const float* relu_src, float* dx, int N, int H, int W, int C, int Ko, int R,
+                                               int S, int stride, int pad, const float* bn_sub, const float* bn_beta,
+                                               const float* bn_beta2, float* sums, float* ws, size_t ws_bytes,
+                                               hipStream_t stream) {
+  CXRK_CHECK_ARG(relu_src && bn_beta && sums && aligned16(bn_beta) && (!bn_beta2 || aligned16(bn_beta2)) && (!bn_sub || aligned16(bn_sub)));
+  CXRK_CHECK_ARG(!(R == 1 && stride == 2));
+  const long np = dgrad_bn_parts(N, H, W, C, stride);
+  if (ws == nullptr || ws_bytes < (size_t)np * 3 * C * sizeof(float)) return CXRK_ERR_WS;
+  const int rc = conv_bwd_data_impl(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R, S, stride, pad, ws, bn_sub, bn_beta,
+                                    bn_beta2, stream);
+  if (rc != CXRK_OK) return rc;
+  hipLaunchKernelGGL(bn_part_final_kernel, dim3(ceil_div(C, 64), 3), dim3(1024), 0, stream, ws, (int)np, C, sums);
+  CXRK_LAUNCH_CHECK();
   return CXRK_OK;
 }
 

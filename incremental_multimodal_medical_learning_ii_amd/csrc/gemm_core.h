@@ -40,6 +40,10 @@ struct EpiParams {
   // optional output-row remap (stride-2 dgrad parity classes): GEMM row (n,a,b) -> pixel (n, 2a+ph, 2b+pw) of [N,H,W]
   int rm_on, rm_Hs, rm_Ws, rm_H, rm_W, rm_ph, rm_pw;
   int vec;  // set by launch_gemm: every pointer / leading dimension allows 16-byte row accesses
+  // optional fused BatchNorm-backward reductions over the rows of this launch (needs auxmode 1, vec): with v the stored
+  // value and y = aux,   S0[c] = sum v,   S1[c] = sum v*(y - sub - beta[c]),   S2[c] = sum v*(sub - beta2[c]).
+  // Per-wave partials go to bn_part[(mt*WM + wm)][3][N]; a second kernel adds them up (deterministic).
+  float* bn_part; const float* bn_sub; long bn_ldsub; const float* bn_beta; const float* bn_beta2;
 };
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -470,6 +474,13 @@ __global__ __launch_bounds__(NTHREADS, CXRK_OCC) void gemm_f32_kernel(typename L
     if (ep.vec) bv = *reinterpret_cast<const float4*>(ep.bias + col);
     else { bv.x = ep.bias[col]; if (col + 1 < N) bv.y = ep.bias[col + 1]; if (col + 2 < N) bv.z = ep.bias[col + 2]; if (col + 3 < N) bv.w = ep.bias[col + 3]; }
   }
+  float bs[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float bb1[4] = {0.f, 0.f, 0.f, 0.f}, bb2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ep.bn_part && col < N) {
+    const float4 t1 = *reinterpret_cast<const float4*>(ep.bn_beta + col);
+    bb1[0] = t1.x; bb1[1] = t1.y; bb1[2] = t1.z; bb1[3] = t1.w;
+    if (ep.bn_beta2) { const float4 t2 = *reinterpret_cast<const float4*>(ep.bn_beta2 + col); bb2[0] = t2.x; bb2[1] = t2.y; bb2[2] = t2.z; bb2[3] = t2.w; }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -505,6 +516,16 @@ __global__ __launch_bounds__(NTHREADS, CXRK_OCC) void gemm_f32_kernel(typename L
           const float ax[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] = ep.auxmode == 1 ? (ax[q] > 0.f ? v[q] : 0.f) : v[q] * gelu_erf_grad(ax[q]);
+          if (ep.bn_part) {
+            float sb[4] = {0.f, 0.f, 0.f, 0.f};
+            if (ep.bn_sub) { const float4 s4 = *reinterpret_cast<const float4*>(ep.bn_sub + row * ep.bn_ldsub + col); sb[0] = s4.x; sb[1] = s4.y; sb[2] = s4.z; sb[3] = s4.w; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              bs[0][q] += v[q];
+              bs[1][q] += v[q] * (ax[q] - sb[q] - bb1[q]);
+              bs[2][q] += v[q] * (sb[q] - bb2[q]);
+            }
+          }
         }
         *reinterpret_cast<float4*>(C + row * ep.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
@@ -523,6 +544,22 @@ __global__ __launch_bounds__(NTHREADS, CXRK_OCC) void gemm_f32_kernel(typename L
       }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if (ep.bn_part) {  // add the four row-quads of the wave (lanes c4, c4+16, c4+32, c4+48), lanes 0..15 write
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t = bs[k][q];
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        bs[k][q] = t;
+      }
+    if (rq == 0 && col < N) {
+      float* dst = ep.bn_part + ((long)(mt * WM + wm) * 3) * N + col;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<float4*>(dst + (long)k * N) = make_float4(bs[k][0], bs[k][1], bs[k][2], bs[k][3]);
+    }
   }
 }
 

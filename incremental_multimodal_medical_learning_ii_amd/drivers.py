@@ -1,0 +1,172 @@
+"""Driver loops with the same schedule as the reference's `ZERO_JOINT_BOUNDS.py:62-72`, `CLASS_INCREMENTAL.py:66-97`
+and `DATA_INCREMENTAL.py:74-97` (hyper-parameters as arguments instead of literals; `playsound` dropped).
+
+    python -m incremental_multimodal_medical_learning_ii_amd.drivers zero-joint --epochs 2 --batch-size 1024
+    python -m incremental_multimodal_medical_learning_ii_amd.drivers class-inc --more-labels
+    python -m incremental_multimodal_medical_learning_ii_amd.drivers data-inc --parts 5
+
+Without a pre-computed CheXpert embedding dataset (`--dataset-root`), synthetic loaders of the same shape are used
+and CXR-BERT is the synthetic-weight model (`CXRK_SYNTHETIC_WEIGHTS=1` semantics)."""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import Trainer as TR
+from .DataRetrieval import CHEXPERT_COMPETITION_CLASSES, basic_create_prompts, create_prompts
+
+
+def _seed(seed_value: int = 27):  # the reference fixes every seed to 27 (ZERO_JOINT_BOUNDS.py:9-14)
+    torch.manual_seed(seed_value)
+    random.seed(seed_value)
+    np.random.seed(seed_value)
+
+
+def _setup(args, kind):
+    device = torch.device("cuda")
+    if args.dataset_root:
+        if kind == "joint":
+            out = TR.Trainer.preprocessing(True, args.xrays_position, args.single_prompt, args.batch_size, args.lr, args.epochs,
+                                           "standard", dataset_root=args.dataset_root, log_root=args.log_root)
+        elif kind == "class":
+            out = TR.Trainer.preprocessing_class_incremental(True, args.xrays_position, args.single_prompt, args.batch_size, args.lr,
+                                                             args.epochs, "standard", args.mode, args.cl, True, args.threshold,
+                                                             args.threshold_scheduling, args.adder, args.more_labels,
+                                                             dataset_root=args.dataset_root, log_root=args.log_root)
+        else:
+            out = TR.Trainer.preprocessing_data_incremental(True, args.xrays_position, args.single_prompt, args.batch_size, args.lr,
+                                                            args.parts, args.epochs, "standard", "data-inc", args.cl, True,
+                                                            args.threshold, args.threshold_scheduling, args.adder,
+                                                            dataset_root=args.dataset_root, log_root=args.log_root)
+        writer, class_names, train_loader, val_loader, test_loader, prompts, _ = out
+    else:
+        class_names = list(CHEXPERT_COMPETITION_CLASSES)
+        prompts = basic_create_prompts(class_names) if args.single_prompt else create_prompts(class_names)
+        train_loader, val_loader, test_loader = TR.Trainer.synthetic_loaders(args.n_train, args.n_eval, args.n_eval, args.batch_size)
+        if kind == "class":
+            train_loader = (TR.Trainer.split_dataloader_data_incremental(train_loader, 5) if args.mode == "class-pos-neg"
+                            else TR.Trainer.split_dataloader_by_label(train_loader, args.batch_size))
+        elif kind == "data":
+            train_loader = TR.Trainer.split_dataloader_data_incremental(train_loader, args.parts)
+        writer = TR._make_writer(os.path.join(args.log_root, "synthetic-" + kind))
+    os.environ.setdefault("CXRK_SYNTHETIC_WEIGHTS", "1" if not args.pretrained_text else "0")
+    from .health_multimodal.text import get_cxr_bert_inference
+    engine = get_cxr_bert_inference(args.pretrained_text, device="cuda")
+    trainer = TR.Trainer(args.single_prompt, prompts, class_names, "standard", args.lr, device, writer, bert_encoder=engine)
+    return trainer, writer, train_loader, val_loader, test_loader
+
+
+def zero_joint_bounds(args):
+    _seed()
+    if args.epochs == 0:  # zero-shot: no adapters (Trainer.py:294-303)
+        TR.IMAGE_MODEL = TR.TEXT_MODEL = False
+    trainer, writer, train_loader, val_loader, test_loader = _setup(args, "joint")
+    criterion = nn.BCEWithLogitsLoss()
+    metrics = None
+    try:
+        if args.epochs > 0:
+            for epoch in range(1, args.epochs + 1):
+                trainer.train(train_loader, criterion, epoch, args.cl, args.threshold, actual_task=epoch)
+                trainer.val(val_loader, criterion, epoch, args.epochs, mode="joint", tasks_order=None)
+                metrics = trainer.test(test_loader, criterion, epoch, args.epochs, mode="joint", tasks_order=None)
+        else:
+            trainer.val(val_loader, criterion, 0, 0, mode="zero", tasks_order=None)
+            metrics = trainer.test(test_loader, criterion, 0, 0, mode="zero", tasks_order=None)
+    finally:
+        if args.epochs > 0:
+            trainer.save()
+    return trainer, metrics
+
+
+def class_incremental(args):
+    _seed()
+    trainer, writer, train_loader, val_loader, test_loader = _setup(args, "class")
+    criterion = nn.BCEWithLogitsLoss()
+    tasks_order = [0, 1, 2, 3, 4]
+    last_batch = count = 0
+    threshold = args.threshold
+    metrics = None
+    try:
+        for actual_task in range(1, len(tasks_order) + 1):
+            for epoch in range(1, args.epochs + 1):
+                count += 1
+                threshold = threshold + args.adder
+                if args.threshold_scheduling and args.cl is not None:
+                    writer.add_scalar("monitor-resets/threshold-scheduling", threshold, count)
+                if args.cl == "profCL" and actual_task > 1:
+                    trainer.model_copy()
+                fn = trainer.train_class_more_labels_incremental if args.more_labels else trainer.train_class_incremental
+                last_batch = fn(train_loader[actual_task - 1], criterion, epoch, args.cl, threshold, tasks_order[actual_task - 1],
+                                last_batch, actual_task)
+                if args.cl == "profCL" and actual_task > 1:
+                    trainer.profIncremental(epoch, args.epochs, actual_task, threshold)
+            trainer.val(val_loader, criterion, actual_task, args.epochs, mode=args.mode, tasks_order=tasks_order)
+            metrics = trainer.test(test_loader, criterion, actual_task, args.epochs, mode=args.mode, tasks_order=tasks_order)
+    finally:
+        trainer.save()
+    return trainer, metrics
+
+
+def data_incremental(args):
+    _seed()
+    trainer, writer, train_loader, val_loader, test_loader = _setup(args, "data")
+    criterion = nn.BCEWithLogitsLoss()
+    count = 0
+    threshold = args.threshold
+    metrics = None
+    try:
+        for part in range(1, args.parts + 1):
+            for epoch in range(1, args.epochs + 1):
+                count += 1
+                threshold = threshold + args.adder
+                if args.cl == "profCL":
+                    trainer.model_copy()
+                trainer.train(train_loader[part - 1], criterion, epoch, args.cl, threshold, part=part, epochs=args.epochs,
+                              actual_task=part)
+                if args.cl == "profCL":
+                    trainer.profIncremental(epoch, args.epochs, part, threshold)
+            train_loader[part - 1] = None
+            trainer.val(val_loader, criterion, part, args.parts, mode="data-inc", tasks_order=part)
+            metrics = trainer.test(test_loader, criterion, part, args.parts, mode="data-inc", tasks_order=part)
+    finally:
+        trainer.save()
+    return trainer, metrics
+
+
+def make_parser():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("which", choices=["zero-joint", "class-inc", "data-inc"])
+    ap.add_argument("--batch-size", type=int, default=6144)      # ZERO_JOINT_BOUNDS.py:20
+    ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--epochs", type=int, default=10)
+    ap.add_argument("--parts", type=int, default=5)
+    ap.add_argument("--mode", default="class-pos-neg", choices=["class-pos-neg", "class-pos"])
+    ap.add_argument("--more-labels", action="store_true")
+    ap.add_argument("--single-prompt", action="store_true")
+    ap.add_argument("--xrays-position", default="all")
+    ap.add_argument("--cl", default=None, choices=[None, "myCL", "profCL"])
+    ap.add_argument("--threshold", type=float, default=0.5)
+    ap.add_argument("--adder", type=float, default=0.001)
+    ap.add_argument("--threshold-scheduling", action="store_true")
+    ap.add_argument("--dataset-root", default=None)
+    ap.add_argument("--pretrained-text", default=None)
+    ap.add_argument("--log-root", default="runs")
+    ap.add_argument("--n-train", type=int, default=61440)
+    ap.add_argument("--n-eval", type=int, default=4096)
+    return ap
+
+
+def main(argv=None):
+    args = make_parser().parse_args(argv)
+    fn = {"zero-joint": zero_joint_bounds, "class-inc": class_incremental, "data-inc": data_incremental}[args.which]
+    _, metrics = fn(args)
+    print("final test metrics:", metrics)
+
+
+if __name__ == "__main__":
+    main()
