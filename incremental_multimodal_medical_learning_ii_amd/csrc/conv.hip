@@ -237,22 +237,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_final_kernel(const float* _
   }
 }
 
-// sums[k][c] = sum_p part[p][k][c], k = 0..2; block = 64 columns x 16 part-lanes
-__global__ __launch_bounds__(1024) void bn_part_final_kernel(const float* __restrict__ part, int nparts, int C,
-                                                             float* __restrict__ sums) {
+// out[z][k][c] = sum over the z-th chunk of parts of part[p][k][c], k = 0..2; block = 64 columns x 16 part-lanes.
+// Run twice (chunks -> 1) so the long partial lists of the 56x56 layers are reduced by many blocks, deterministically.
+__global__ __launch_bounds__(1024) void bn_part_final_kernel(const float* __restrict__ part, int nparts, int chunk, int C,
+                                                             float* __restrict__ out) {
   __shared__ float sh[16][64];
   const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl, k = blockIdx.y;
+  const int c = blockIdx.x * 64 + cl, k = blockIdx.y, z = blockIdx.z;
+  const int p0 = z * chunk, p1 = min(nparts, p0 + chunk);
   float a = 0.f;
   if (c < C)
-    for (int p = pl; p < nparts; p += 16) a += part[((long)p * 3 + k) * C + c];
+    for (int p = p0 + pl; p < p1; p += 16) a += part[((long)p * 3 + k) * C + c];
   sh[pl][cl] = a;
   __syncthreads();
   if (pl == 0 && c < C) {
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += sh[i][cl];
-    sums[(long)k * C + c] = t;
+    out[((long)z * 3 + k) * C + c] = t;
   }
 }
 
@@ -404,7 +406,7 @@ extern "C" int cxrk_conv_bn_act_bwd_data(const float* dy, const float* w_scaled,
 }
 
 extern "C" size_t cxrk_conv_bwd_data_bnsum_ws_bytes(int N, int H, int W, int C, int stride) {
-  return (size_t)dgrad_bn_parts(N, H, W, C, stride) * 3 * C * sizeof(float);
+  return (size_t)(dgrad_bn_parts(N, H, W, C, stride) + 64) * 3 * C * sizeof(float);
 }
 
 // Data gradient + the BatchNorm-backward channel sums of the unit that PRODUCED relu_src, in one pass:
@@ -418,12 +420,20 @@ extern "C" int cxrk_conv_bn_act_bwd_data_bnsum(const float* dy, const float* w_s
   CXRK_CHECK_ARG(relu_src && bn_beta && sums && aligned16(bn_beta) && (!bn_beta2 || aligned16(bn_beta2)) && (!bn_sub || aligned16(bn_sub)));
   CXRK_CHECK_ARG(!(R == 1 && stride == 2));
   const long np = dgrad_bn_parts(N, H, W, C, stride);
-  if (ws == nullptr || ws_bytes < (size_t)np * 3 * C * sizeof(float)) return CXRK_ERR_WS;
+  if (ws == nullptr || ws_bytes < (size_t)(np + 64) * 3 * C * sizeof(float)) return CXRK_ERR_WS;
   const int rc = conv_bwd_data_impl(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R, S, stride, pad, ws, bn_sub, bn_beta,
                                     bn_beta2, stream);
   if (rc != CXRK_OK) return rc;
-  hipLaunchKernelGGL(bn_part_final_kernel, dim3(ceil_div(C, 64), 3), dim3(1024), 0, stream, ws, (int)np, C, sums);
+  int Z = ceil_div(np, 512); if (Z > 64) Z = 64; if (Z < 1) Z = 1;
+  const int chunk = ceil_div(np, Z);
+  Z = ceil_div(np, chunk);
+  float* tmp = ws + np * 3 * C;
+  hipLaunchKernelGGL(bn_part_final_kernel, dim3(ceil_div(C, 64), 3, Z), dim3(1024), 0, stream, ws, (int)np, chunk, C, Z > 1 ? tmp : sums);
   CXRK_LAUNCH_CHECK();
+  if (Z > 1) {
+    hipLaunchKernelGGL(bn_part_final_kernel, dim3(ceil_div(C, 64), 3, 1), dim3(1024), 0, stream, tmp, Z, Z, C, sums);
+    CXRK_LAUNCH_CHECK();
+  }
   return CXRK_OK;
 }
 

@@ -156,11 +156,13 @@ def _forward(specs, blocks, p: Sequence[torch.Tensor], bufs: Sequence[torch.Tens
     return emb, patch, state
 
 
-def _unit_bwd(i, s, fold, p, bufs, x, dy, y, sub, N, H, W, grads):
+def _unit_bwd(i, s, fold, p, bufs, x, dy, y, sub, N, H, W, grads, sums=None):
     """Parameter gradients of conv+BN unit i.  x: its input [N,H,W,cpad]; dy: masked gradient w.r.t. its BN output;
-    (y - sub) equals the BN output wherever dy != 0 (y = post-ReLU output, sub = the residual that was added)."""
-    sums = torch.empty(2, s.cout, dtype=torch.float32, device=dy.device)
-    K.bn_bwd_reduce(dy, y, sub, p[3 * i + 2], sums[0], sums[1])
+    (y - sub) equals the BN output wherever dy != 0 (y = post-ReLU output, sub = the residual that was added).
+    `sums` = (sum dy, sum dy*(y_bn - beta)) when the data-gradient kernel that produced dy already reduced them."""
+    if sums is None:
+        sums = torch.empty(2, s.cout, dtype=torch.float32, device=dy.device)
+        K.bn_bwd_reduce(dy, y, sub, p[3 * i + 2], sums[0], sums[1])
     w = _filter_rsc(p[3 * i])
     dw = torch.empty_like(w)
     dg, db = torch.empty_like(p[3 * i + 1]), torch.empty_like(p[3 * i + 2])
@@ -170,10 +172,17 @@ def _unit_bwd(i, s, fold, p, bufs, x, dy, y, sub, N, H, W, grads):
     grads[3 * i + 1], grads[3 * i + 2] = dg, db
 
 
-def _dgrad(i, s, fold, dy, residual, relu_src, N, H, W):
+def _dgrad(i, s, fold, dy, residual, relu_src, N, H, W, bn=None):
+    """Data gradient of unit i.  bn = (sub, beta, beta2): also reduce, in the same epilogue, the BN-backward channel
+    sums of the unit(s) that produced `relu_src` -> returns (dx, sums[3,C])."""
     dx = torch.empty(N, H, W, s.cpad, dtype=torch.float32, device=dy.device)
-    K.conv_bwd_data(dy, fold.ws(i, s), residual, relu_src, dx, N, H, W, s.cpad, s.cout, s.k, s.k, s.stride, s.pad)
-    return dx
+    if bn is None:
+        K.conv_bwd_data(dy, fold.ws(i, s), residual, relu_src, dx, N, H, W, s.cpad, s.cout, s.k, s.k, s.stride, s.pad)
+        return dx
+    sums = torch.empty(3, s.cpad, dtype=torch.float32, device=dy.device)
+    K.conv_bwd_data_bnsum(dy, fold.ws(i, s), residual, relu_src, dx, N, H, W, s.cpad, s.cout, s.k, s.k, s.stride, s.pad,
+                          bn[0], bn[1], bn[2], sums)
+    return dx, sums
 
 
 def _backward(specs, blocks, p, bufs, state, demb: torch.Tensor, dpatch: Optional[torch.Tensor]):
@@ -195,27 +204,44 @@ def _backward(specs, blocks, p, bufs, state, demb: torch.Tensor, dpatch: Optiona
     grads[3 * ns + 1] = K.colsum(dpj2, torch.empty_like(p[3 * ns + 1]))
     g = K.linear_bwd_data(dpj2, w3m, aux=pj1m, auxmode=K.AUX_RELU_MASK).view(N, h, w, -1)
     _unit_bwd(ip, specs[ip], fold, p, bufs, last, g, pj1, None, N, h, w, grads)
-    g = _dgrad(ip, specs[ip], fold, g, None, last, N, h, w)
-    for bi in reversed(range(len(blocks))):
+
+    def beta(i):
+        return p[3 * i + 2]
+
+    def block_bn(bi):
+        """(sub, beta, beta2) for the gradient w.r.t. block bi's output: its conv3 unit (y_bn = out - identity) and, when
+        the identity is a downsample unit, that unit too (y_bn = identity)."""
+        blk = blocks[bi]
+        idt = binfo[bi][4] if blk["ds"] is not None else binfo[bi][0]
+        return (idt, beta(blk["c3"]), beta(blk["ds"]) if blk["ds"] is not None else None)
+
+    nb = len(blocks)
+    g, gs = _dgrad(ip, specs[ip], fold, g, None, last, N, h, w, bn=block_bn(nb - 1))
+    for bi in reversed(range(nb)):
         blk = blocks[bi]
         cur, o1, o2, out, idt, hi, wi, h2, w2 = binfo[bi]
-        binfo[bi] = None
         s1, s2, s3 = specs[blk["c1"]], specs[blk["c2"]], specs[blk["c3"]]
-        # out = relu(bn3(conv3(o2)) + identity): where g != 0, bn3 output = out - identity
-        _unit_bwd(blk["c3"], s3, fold, p, bufs, o2, g, out, idt if idt is not None else cur, N, h2, w2, grads)
-        d2 = _dgrad(blk["c3"], s3, fold, g, None, o2, N, h2, w2)
-        _unit_bwd(blk["c2"], s2, fold, p, bufs, o1, d2, o2, None, N, hi, wi, grads)
-        d1 = _dgrad(blk["c2"], s2, fold, d2, None, o1, N, hi, wi)
+        # out = relu(bn3(conv3(o2)) + identity): g (already masked by out > 0) is dy of bn3 and of the downsample BN;
+        # their channel sums gs were reduced by the kernel that produced g
+        _unit_bwd(blk["c3"], s3, fold, p, bufs, o2, g, out, idt if idt is not None else cur, N, h2, w2, grads, sums=gs[0:2])
+        d2, q2 = _dgrad(blk["c3"], s3, fold, g, None, o2, N, h2, w2, bn=(None, beta(blk["c2"]), None))
+        _unit_bwd(blk["c2"], s2, fold, p, bufs, o1, d2, o2, None, N, hi, wi, grads, sums=q2[0:2])
+        d1, q1 = _dgrad(blk["c2"], s2, fold, d2, None, o1, N, hi, wi, bn=(None, beta(blk["c1"]), None))
         del d2
-        _unit_bwd(blk["c1"], s1, fold, p, bufs, cur, d1, o1, None, N, hi, wi, grads)
+        _unit_bwd(blk["c1"], s1, fold, p, bufs, cur, d1, o1, None, N, hi, wi, grads, sums=q1[0:2])
         if blk["ds"] is not None:
             sd = specs[blk["ds"]]
-            _unit_bwd(blk["ds"], sd, fold, p, bufs, cur, g, idt, None, N, hi, wi, grads)
+            _unit_bwd(blk["ds"], sd, fold, p, bufs, cur, g, idt, None, N, hi, wi, grads, sums=torch.stack([gs[0], gs[2]]))
             res = _dgrad(blk["ds"], sd, fold, g, None, None, N, hi, wi)
         else:
             res = g
-        g = _dgrad(blk["c1"], s1, fold, d1, res, cur, N, hi, wi)
+        binfo_prev_bn = block_bn(bi - 1) if bi > 0 else None
+        if binfo_prev_bn is not None:
+            g, gs = _dgrad(blk["c1"], s1, fold, d1, res, cur, N, hi, wi, bn=binfo_prev_bn)
+        else:
+            g, gs = _dgrad(blk["c1"], s1, fold, d1, res, cur, N, hi, wi), None
         del d1, res
+        binfo[bi] = None
     ds = K.maxpool_bwd(g, idx, stem, True)
     _unit_bwd(0, specs[0], fold, p, bufs, x0, ds, stem, None, N, H, W, grads)
     return grads

@@ -252,6 +252,24 @@ def bn_bwd_reduce(dy, y, sub, beta, sumdy, sumdyy):
                                  _p(sumdy), _p(sumdyy), _p(ws), ws.numel() * 4, _stream()), "cxrk_bn_bwd_reduce")
 
 
+def conv_bwd_data_bnsum(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R, S, stride, pad, bn_sub, bn_beta, bn_beta2, sums):
+    """conv_bwd_data + the BN-backward channel sums of the unit that produced `relu_src` (sums [3,C])."""
+    lib = _lib.load()
+    ws = workspace(lib.cxrk_conv_bwd_data_bnsum_ws_bytes(N, H, W, C, stride), dy.device)
+    ev = None
+    if profiler.on:
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        ev = profiler.bracket(f"gemm_f32_kernel<ConvDgradKC,ConvFilterMC,{'4,1' if C <= 64 else '2,2'}>",
+                              2.0 * N * Ho * Wo * Ko * R * S * C)
+    rc = lib.cxrk_conv_bn_act_bwd_data_bnsum(_p(_chk(dy, "conv.dy")), _p(w_scaled), _p(residual), _p(relu_src), _p(dx), N, H, W, C,
+                                             Ko, R, S, stride, pad, _p(bn_sub), _p(bn_beta), _p(bn_beta2), _p(sums), _p(ws),
+                                             ws.numel() * 4, _stream())
+    if ev is not None:
+        ev.record()
+    check(rc, f"cxrk_conv_bn_act_bwd_data_bnsum(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
+    return dx
+
+
 def conv_bwd_params(x, dy, w, scale, rstd, rmean, sumdy, gamma, sumdyy, dw, dgamma, dbeta, accumulate, N, H, W, C, Cpad,
                     Ko, R, S, stride, pad):
     lib = _lib.load()

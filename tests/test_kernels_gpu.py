@@ -149,6 +149,15 @@ def test_conv_bn_relu_fwd_bwd(cfg):
         else:
             K.conv_bwd_data(gyd, ws, add, xd, dxd, N, H, W, C, Ko, R, R, stride, pad)
             close(K.nhwc_to_nchw(dxd), (x.grad + K.nhwc_to_nchw(add).cpu()) * (x.detach() > 0), tol=5e-5, what="dgrad+res+mask")
+            # same launch with the fused BatchNorm-backward channel sums
+            sub, b1, b2 = rnd(N, H, W, C, seed=12).to(DEV), rnd(C, seed=13).to(DEV), rnd(C, seed=14).to(DEV)
+            sums, dx2 = torch.empty(3, C, device=DEV), torch.empty_like(dxd)
+            K.conv_bwd_data_bnsum(gyd, ws, add, xd, dx2, N, H, W, C, Ko, R, R, stride, pad, sub, b1, b2, sums)
+            assert torch.equal(dx2, dxd)
+            v = dxd.double().view(-1, C)
+            close(sums[0], v.sum(0).float(), tol=5e-5, what="bnsum S0")
+            close(sums[1], (v * (xd.double().view(-1, C) - sub.double().view(-1, C) - b1.double())).sum(0).float(), tol=5e-5, what="bnsum S1")
+            close(sums[2], (v * (sub.double().view(-1, C) - b2.double())).sum(0).float(), tol=5e-5, what="bnsum S2")
 
 
 def test_maxpool_spatial_mean():
