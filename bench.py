@@ -113,8 +113,8 @@ def main():
     import faulthandler
     faulthandler.enable()
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)   # a stuck phase shows where it is stuck
-    torch.set_num_threads(min(usable_cores(), 16))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.set_num_threads(max(1, min(usable_cores() // max(1, world), 16)))   # ranks share the host cores
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist

@@ -24,6 +24,10 @@ timeit(lambda: K.linear_fwd(x768, wq, out=y2304), 2 * T * 768 * 2304, "dense NT 
 timeit(lambda: K.linear_bwd_data(y3072, w1, out=y768), 2 * T * 768 * 3072, "dense NN  32768x768x3072")
 dw = torch.empty(3072, 768, device=dev)
 timeit(lambda: K.linear_bwd_weight(y3072, x768, dw), 2 * T * 768 * 3072, "dense TN  3072x768x32768 (split-K)")
+xa = torch.randn(200704, 1152, device=dev); wa = torch.randn(128, 1152, device=dev); ya = torch.empty(200704, 128, device=dev)
+timeit(lambda: K.linear_fwd(xa, wa, out=ya), 2 * 200704 * 128 * 1152, "dense NT  200704x128x1152 (= 28x28 128->128 3x3 as a GEMM)")
+xb = torch.randn(802816, 64, device=dev); wb = torch.randn(256, 64, device=dev); yb = torch.empty(802816, 256, device=dev)
+timeit(lambda: K.linear_fwd(xb, wb, out=yb), 2 * 802816 * 256 * 64, "dense NT  802816x256x64   (= 56x56 64->256 1x1 as a GEMM)")
 # conv shapes at batch 256 (same per-CU behaviour as 1024, 4x shorter)
 N = 256
 def conv_case(H, C, Ko, R, stride, tag):

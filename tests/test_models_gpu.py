@@ -275,3 +275,45 @@ def test_joint_step_vs_cpu_oracle():
         for k, v in d.items():
             if v.requires_grad:
                 assert rel(sd[k], v) < TOL, k
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 1
+def test_zero_shot_engine_config1():
+    """ZERO_JOINT_BOUNDS-style zero-shot (BASELINE.json configs[0], scaled to 8 images): synthetic 224x224 images x 5
+    CheXpert class prompt sets through ImageTextInferenceEngine vs the CPU oracle (trash/lower_bound_mcs.py:79-117)."""
+    from incremental_multimodal_medical_learning_ii_amd.DataRetrieval import CHEXPERT_COMPETITION_CLASSES, create_prompts
+    from incremental_multimodal_medical_learning_ii_amd.health_multimodal.image import ImageInferenceEngine
+    from incremental_multimodal_medical_learning_ii_amd.health_multimodal.image.data.transforms import create_chest_xray_transform_for_inference
+    from incremental_multimodal_medical_learning_ii_amd.health_multimodal.text import SyntheticTokenizer, TextInferenceEngine
+    from incremental_multimodal_medical_learning_ii_amd.health_multimodal.vlp import ImageTextInferenceEngine
+    from oracle import ref_image, ref_loss, ref_text
+    cfg = CXRBertConfig(vocab_size=2048, hidden_size=128, num_attention_heads=2, intermediate_size=256,
+                        num_hidden_layers=2, max_position_embeddings=32)
+    tm, im = CXRBertModel(cfg).eval(), get_biovil_resnet(None).eval()
+    syn.fill_module_(tm)
+    syn.fill_module_(im)
+    isd = {k: v.clone() for k, v in im.state_dict().items()}
+    tsd = {k: v.clone() for k, v in tm.state_dict().items()}
+    tok = SyntheticTokenizer(2048)
+    eng = ImageTextInferenceEngine(ImageInferenceEngine(im.to(DEV), create_chest_xray_transform_for_inference(512, 480)),
+                                   TextInferenceEngine(tok, tm.to(DEV)))
+    classes = list(CHEXPERT_COMPETITION_CLASSES)
+    prompts = create_prompts(classes)
+    images = syn.synthetic_images(8, 224, seed=5)
+    scores = eng.get_similarity_scores_from_tensors(images.to(DEV), [prompts[c]["positive"] for c in classes])
+    assert scores.shape == (8, 5)
+    img_ref = ref_image.image_model_forward(isd, images)
+    txt_ref = []
+    for c in classes:
+        t = tok.batch_encode_plus([p.rstrip("!?.") for p in prompts[c]["positive"]])
+        txt_ref.append(ref_text.cxrbert_projected(tsd, t.input_ids, t.attention_mask, 2, 2).mean(0))
+    ref = ref_loss.zero_shot_scores(img_ref, torch.stack(txt_ref))
+    assert rel(scores, ref) < TOL, rel(scores, ref)
+    assert torch.equal(scores.argmax(1).cpu(), ref.argmax(1))
+    # single-image API through a file (vlp/inference_engine.py:31-57)
+    import numpy as np, tempfile, os
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "xray.npy")
+        np.save(path, (images[0, 0].numpy() * 255).astype(np.uint8))
+        s = eng.get_similarity_score_from_raw_data(path, prompts[classes[0]]["positive"])
+    assert isinstance(s, float) and -1.0 <= s <= 1.0

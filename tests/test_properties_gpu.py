@@ -1,0 +1,103 @@
+"""Size-independent properties at (near) BASELINE.json sizes, where the CPU oracle would take too long:
+batch independence and padding invariance of the text encoder, scale invariance and zero-sum structure of the InfoNCE
+gradient at global batch 1024, linearity of the convolution in its filter at a full-size ResNet layer, optimiser fixed
+points, and loss = ln(B) for identical embeddings."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from incremental_multimodal_medical_learning_ii_amd import functional as Fh  # noqa: E402
+from incremental_multimodal_medical_learning_ii_amd import kernels as K  # noqa: E402
+from incremental_multimodal_medical_learning_ii_amd import optim as cxr_optim  # noqa: E402
+from incremental_multimodal_medical_learning_ii_amd import synthetic as syn  # noqa: E402
+from incremental_multimodal_medical_learning_ii_amd.health_multimodal.text import CXRBertConfig, CXRBertModel  # noqa: E402
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    return float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-30))
+
+
+def test_infonce_structure_at_global_batch_1024():
+    B, D, tau = 1024, 128, 0.07
+    g = torch.Generator().manual_seed(1)
+    I = torch.randn(B, D, generator=g).to(DEV).requires_grad_(True)
+    T = torch.randn(B, D, generator=g).to(DEV).requires_grad_(True)
+    loss = Fh.infonce_loss(I, T, tau)
+    loss.backward()
+    assert 0.5 * math.log(B) < loss.item() < 3 * math.log(B)
+    # the loss only sees normalised embeddings: the gradient is orthogonal to each row (scale invariance) ...
+    assert float(((I * I.grad).sum(1).abs().max()) / (I.grad.norm(dim=1).max() * I.norm(dim=1).max())) < 1e-5
+    # ... scaling the inputs leaves the loss unchanged and scales the gradient by 1/s
+    I2 = (3.0 * I.detach()).requires_grad_(True)
+    loss2 = Fh.infonce_loss(I2, T.detach(), tau)
+    loss2.backward()
+    assert abs(loss2.item() - loss.item()) < 1e-5 and rel(I2.grad * 3.0, I.grad) < 1e-4
+    # symmetric in its two arguments
+    assert abs(Fh.infonce_loss(T.detach(), I.detach(), tau).item() - loss.item()) < 1e-5
+    # identical, mutually orthogonal embeddings at tau -> 0+: every row is classified perfectly; at tau=1 with identical
+    # rows everywhere the logits are constant and loss = ln(B)
+    ones = torch.ones(B, D, device=DEV)
+    assert abs(Fh.infonce_loss(ones, ones, 1.0).item() - math.log(B)) < 1e-4
+
+
+def test_text_encoder_batch_independence_and_padding_invariance():
+    model = CXRBertModel(CXRBertConfig(num_hidden_layers=2)).eval()
+    syn.fill_module_(model)
+    model.to(DEV)
+    ids, mask = syn.synthetic_tokens(256, 32, ragged=True)
+    ids, mask = ids.to(DEV), mask.to(DEV)
+    with torch.no_grad():
+        e = model.get_projected_text_embeddings(ids, mask, normalize_embeddings=False)
+        perm = torch.randperm(256, generator=torch.Generator().manual_seed(0)).to(DEV)
+        e_perm = model.get_projected_text_embeddings(ids[perm], mask[perm], normalize_embeddings=False)
+        assert torch.equal(e_perm, e[perm])                      # bit-exact: rows never mix
+        junk = torch.where(mask == 0, torch.randint_like(ids, 5, 30000), ids)
+        e_junk = model.get_projected_text_embeddings(junk, mask, normalize_embeddings=False)
+        assert rel(e_junk, e) < 1e-6                            # padded tokens cannot influence the CLS embedding
+        n = model.get_projected_text_embeddings(ids, mask, normalize_embeddings=True)
+        assert rel(n.norm(dim=1), torch.ones(256, device=DEV)) < 1e-5
+
+
+def test_conv_is_linear_in_its_filter_at_full_layer_size():
+    # layer2 3x3 (128->128 at 28x28) at batch 256: y(w1 + 2*w2) = y(w1) + 2*y(w2) with zero shift and no ReLU
+    N, H, C, Ko = 256, 28, 128, 128
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(N, H, H, C, generator=g).to(DEV)
+    w1 = (torch.randn(Ko, 3, 3, C, generator=g) * 0.03).to(DEV)
+    w2 = (torch.randn(Ko, 3, 3, C, generator=g) * 0.03).to(DEV)
+    z = torch.zeros(Ko, device=DEV)
+    out = [torch.empty(N, H, H, Ko, device=DEV) for _ in range(3)]
+    for w, y in zip((w1, w2, w1 + 2 * w2), out):
+        K.conv_fwd(x, w.contiguous(), z, None, y, N, H, H, C, Ko, 3, 3, 1, 1, False)
+    assert rel(out[2], out[0] + 2 * out[1]) < 1e-5
+    # data gradient is the adjoint of the forward map: <conv(x,w), dy> = <x, conv^T(dy,w)>
+    dy = torch.randn(N, H, H, Ko, generator=g).to(DEV)
+    dx = torch.empty_like(x)
+    K.conv_bwd_data(dy, w1.contiguous(), None, None, dx, N, H, H, C, Ko, 3, 3, 1, 1)
+    lhs, rhs = (out[0].double() * dy.double()).sum(), (x.double() * dx.double()).sum()
+    assert abs(lhs - rhs) / abs(lhs) < 1e-6
+
+
+def test_optimizer_fixed_points_on_flat_buffers():
+    p = [torch.nn.Parameter(torch.randn(1000, 37, device=DEV)), torch.nn.Parameter(torch.randn(5, device=DEV))]
+    before = [q.detach().clone() for q in p]
+    opt = cxr_optim.Adam(p, lr=1e-2)
+    opt.zero_grad()
+    opt.step()                                   # zero gradient: Adam must not move anything
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, p))
+    (p[0] * 2.0).sum().backward()                # constant gradient 2 on the first tensor only
+    opt.step()
+    ref = [torch.nn.Parameter(b.cpu().clone()) for b in before]   # torch.optim.Adam through the same two steps
+    ropt = torch.optim.Adam(ref, lr=1e-2)
+    for r_ in ref:
+        r_.grad = torch.zeros_like(r_)
+    ropt.step()
+    ref[0].grad = torch.full_like(ref[0], 2.0)
+    ropt.step()
+    assert rel(p[0].detach().cpu(), ref[0].detach()) < 1e-6
+    assert torch.equal(p[1].detach(), before[1])
