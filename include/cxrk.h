@@ -175,6 +175,13 @@ size_t cxrk_weight_reset_ws_bytes(void);
 int cxrk_weight_reset(float* pnew, const float* pold, long n, float threshold, unsigned long long* counters, float* ws,
                       size_t ws_bytes, hipStream_t stream);
 
+/* Contraction precision of every GEMM / implicit-GEMM entry point above (process-wide):
+ *   0 (default) exact fp32: v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain;
+ *   1 split-bf16: operands split into bf16 hi+lo while staged, a*b = hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16
+ *     with fp32 accumulation (~2^-16 relative per product; inputs, outputs and all other kernels stay fp32). */
+int cxrk_set_precision(int mode);
+int cxrk_get_precision(void);
+
 /* Library identification: returns a static string "cxrk <version> gfx950". */
 const char* cxrk_version(void);
 

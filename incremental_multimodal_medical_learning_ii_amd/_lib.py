@@ -61,6 +61,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_sgd": (I, [P, P, L, F, F, F, P]),
     "cxrk_weight_reset_ws_bytes": (Z, []),
     "cxrk_weight_reset": (I, [P, P, L, F, P, P, Z, P]),
+    "cxrk_set_precision": (I, [I]),
+    "cxrk_get_precision": (I, []),
     "cxrk_version": (c_char_p, []),
 }
 
@@ -89,7 +91,27 @@ def load() -> ctypes.CDLL:
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    mode = os.environ.get("CXRK_PRECISION", "fp32")
+    if mode not in PRECISIONS:
+        raise CxrkError(f"CXRK_PRECISION={mode!r}: expected one of {sorted(PRECISIONS)}")
+    lib.cxrk_set_precision(PRECISIONS[mode])
     return lib
+
+
+PRECISIONS = {"fp32": 0, "split_bf16": 1}
+
+
+def set_precision(mode: str) -> None:
+    """Contraction precision of every GEMM / convolution: "fp32" (exact fp32 MFMA, default) or "split_bf16"
+    (3x bf16 MFMA per product, fp32 accumulate, ~2^-16 relative per product)."""
+    if mode not in PRECISIONS:
+        raise ValueError(f"precision {mode!r}: expected one of {sorted(PRECISIONS)}")
+    check(load().cxrk_set_precision(PRECISIONS[mode]), "cxrk_set_precision")
+
+
+def get_precision() -> str:
+    v = load().cxrk_get_precision()
+    return {b: a for a, b in PRECISIONS.items()}[v]
 
 
 def check(rc: int, what: str) -> None:

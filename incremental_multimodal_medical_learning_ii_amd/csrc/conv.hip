@@ -309,10 +309,10 @@ extern "C" int cxrk_conv_bn_act_fwd(const float* x, const float* w_scaled, const
   int rc;
   if (Ko <= 64) {
     ConvIm2colKC<256>::P pa{x, g, M, K}; DenseKC<64>::P pb{w_scaled, (long)K, Ko, K};
-    rc = launch_gemm<ConvIm2colKC<256>, DenseKC<64>, 4, 1>(pa, pb, ep, M, Ko, K, 1, stream);
+    rc = launch_gemm<ConvIm2colKC<256>, DenseKC<64>, 4, 1>(pa, pb, ep, M, Ko, K, 1, stream, C <= 4);
   } else {
     ConvIm2colKC<128>::P pa{x, g, M, K}; DenseKC<128>::P pb{w_scaled, (long)K, Ko, K};
-    rc = launch_gemm<ConvIm2colKC<128>, DenseKC<128>, 2, 2>(pa, pb, ep, M, Ko, K, 1, stream);
+    rc = launch_gemm<ConvIm2colKC<128>, DenseKC<128>, 2, 2>(pa, pb, ep, M, Ko, K, 1, stream, C <= 4);
   }
   return rc < 0 ? rc : CXRK_OK;
 }
@@ -474,10 +474,10 @@ extern "C" int cxrk_conv_bn_act_bwd_params(const float* x, const float* dy, cons
   int rc;
   if (Ko <= 64) {
     DenseMC<64>::P pa{dy, (long)Ko, Ko, Kred}; ConvIm2colMC<256>::P pb{x, g, Nc, Kred};
-    rc = launch_gemm<DenseMC<64>, ConvIm2colMC<256>, 1, 4>(pa, pb, ep, Ko, Nc, Kred, sk, stream);
+    rc = launch_gemm<DenseMC<64>, ConvIm2colMC<256>, 1, 4>(pa, pb, ep, Ko, Nc, Kred, sk, stream, Cpad <= 4);
   } else {
     DenseMC<128>::P pa{dy, (long)Ko, Ko, Kred}; ConvIm2colMC<128>::P pb{x, g, Nc, Kred};
-    rc = launch_gemm<DenseMC<128>, ConvIm2colMC<128>, 2, 2>(pa, pb, ep, Ko, Nc, Kred, sk, stream);
+    rc = launch_gemm<DenseMC<128>, ConvIm2colMC<128>, 2, 2>(pa, pb, ep, Ko, Nc, Kred, sk, stream, Cpad <= 4);
   }
   if (rc < 0) return rc;
   hipLaunchKernelGGL(wgrad_reduce_bn_kernel, dim3(Ko, ceil_div(Nc, 1024)), dim3(256), 0, stream, ws, rc, (long)Ko * Nc, R * S, C, Cpad, w,

@@ -48,6 +48,59 @@ struct EpiParams {
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// ---- split-bf16 ("bf16x3") helpers --------------------------------------------------------------------------------
+// x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi): the product a*b is taken as
+// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 MFMA (fp32 accumulate), dropping only a_lo*b_lo (2^-16 relative).
+constexpr int LDH = BK + 8;  // LDS row stride of a bf16 operand tile, in halfwords (80 B: conflict-free ds_read_b128)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
+  const bf16x2 h01 = {(__bf16)v.x, (__bf16)v.y}, h23 = {(__bf16)v.z, (__bf16)v.w};
+  const float r0 = v.x - (float)h01[0], r1 = v.y - (float)h01[1], r2 = v.z - (float)h23[0], r3 = v.w - (float)h23[1];
+  const bf16x2 l01 = {(__bf16)r0, (__bf16)r1}, l23 = {(__bf16)r2, (__bf16)r3};
+  hi.x = __builtin_bit_cast(unsigned, h01); hi.y = __builtin_bit_cast(unsigned, h23);
+  lo.x = __builtin_bit_cast(unsigned, l01); lo.y = __builtin_bit_cast(unsigned, l23);
+}
+// K-contiguous operand: 4 consecutive k of one row -> one 8-byte store per plane
+__device__ __forceinline__ void store2_kc(unsigned short* hi, unsigned short* lo, int row, int k, const float4& v) {
+  uint2 h, l; split4(v, h, l);
+  *reinterpret_cast<uint2*>(hi + row * LDH + k) = h;
+  *reinterpret_cast<uint2*>(lo + row * LDH + k) = l;
+}
+// idx-contiguous operand: the plane keeps the global orientation [k][idx] (row stride TILE+32 halfwords), so the 4
+// consecutive idx of a float4 are ONE 8-byte store per plane; the k-major -> MFMA-operand transpose is done by the
+// reads (ds_read_b64_tr_b16, see frag_mc).
+template <int LDT>
+__device__ __forceinline__ void store2_mc(unsigned short* hi, unsigned short* lo, int idx, int k, const float4& v) {
+  uint2 h, l; split4(v, h, l);
+  *reinterpret_cast<uint2*>(hi + k * LDT + idx) = h;
+  *reinterpret_cast<uint2*>(lo + k * LDT + idx) = l;
+}
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// MFMA 32x32x16 operand fragment (8 bf16: k = 8h..8h+7 of row/col r) for the 32-wide tile starting at `row0`.
+// K-contiguous plane [idx][LDH]: one ds_read_b128.
+__device__ __forceinline__ bf16x8 frag_kc(const unsigned short* plane, int row0, int kc, int lane) {
+  return *reinterpret_cast<const bf16x8*>(plane + (row0 + (lane & 31)) * LDH + kc * 16 + 8 * (lane >> 5));
+}
+// idx-contiguous plane [k][LDT]: two transposing reads.  ds_read_b64_tr_b16 works per 16-lane group on a 4(k) x 16(idx)
+// block: lane 4q+p supplies the address of row q, columns 4p..4p+3, and lane i receives column i of the 4 rows
+// (cdna_hip_programming.md T10).  Group g = lane>>4 covers idx 16*(g&1).. and k 8*(g>>1).. (+4 for the second read).
+// LDT = TILE+32 puts the four rows of a block in disjoint 16-dword bank windows (conflict-free).  EXEC is all ones here.
+template <int LDT>
+__device__ __forceinline__ bf16x8 frag_mc(const unsigned short* plane, int row0, int kc, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+  const unsigned short* a0 = plane + (kc * 16 + 8 * (g >> 1) + q) * LDT + row0 + 16 * (g & 1) + 4 * pp;
+  typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+  const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a0));
+  const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a0 + 4 * LDT));
+  const s16x8 x = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+  return __builtin_bit_cast(bf16x8, x);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Loaders.  TILE = extent of the idx dimension in the block tile.  Every loader exposes
 //   P (host-filled parameters), init(P, idx0, tid), load(k0, v[NV]), store(S, v[NV]).
@@ -56,6 +109,8 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 // X(idx, k) = ptr[idx*ld + k]   (k contiguous)
 template <int TILE>
 struct DenseKC {
+  static constexpr bool KC = true;
+  static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
   static constexpr int NV = TILE / 32;
   static constexpr int LD = TILE + 1;  // LDS row stride (floats)
   struct P { const float* ptr; long ld; int rows; int K; };
@@ -74,6 +129,10 @@ struct DenseKC {
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] = (rp[j] != nullptr && k < K) ? *reinterpret_cast<const float4*>(rp[j] + k) : zero4();
   }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) store2_kc(hi, lo, r0 + j * 32, k4 * 4, v[j]);
+  }
   __device__ __forceinline__ void store(float* S, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -86,6 +145,9 @@ struct DenseKC {
 // X(idx, k) = ptr[k*ld + idx]   (idx contiguous)
 template <int TILE>
 struct DenseMC {
+  static constexpr bool KC = false;
+  static constexpr int LDT = TILE + 32;
+  static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
   static constexpr int NV = TILE / 32;
   static constexpr int LD = TILE + 4;  // LDS row stride (floats)
   static constexpr int VPR = TILE / 4;          // float4 per k-row
@@ -105,6 +167,10 @@ struct DenseMC {
       v[j] = (ok && k < K) ? *reinterpret_cast<const float4*>(base + (long)k * ld_) : zero4();
     }
   }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) store2_mc<LDT>(hi, lo, c4 * 4, kr0 + j * RPP, v[j]);
+  }
   __device__ __forceinline__ void store(float* S, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j)
@@ -122,6 +188,8 @@ struct ConvGeom {
 // fprop A operand: idx = (n,ho,wo), k = (r,s,c) -> x[n][ho*st-pad+r][wo*st-pad+s][c]   (c contiguous)
 template <int TILE>
 struct ConvIm2colKC {
+  static constexpr bool KC = true;
+  static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
   static constexpr int NV = TILE / 32;
   static constexpr int LD = TILE + 1;  // LDS row stride (floats)
   struct P { const float* x; ConvGeom g; int rows; int K; };
@@ -151,6 +219,10 @@ struct ConvIm2colKC {
       v[j] = ok ? *reinterpret_cast<const float4*>(x + off[j] + toff) : zero4();
     }
   }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) store2_kc(hi, lo, r0 + j * 32, k4 * 4, v[j]);
+  }
   __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -163,6 +235,8 @@ struct ConvIm2colKC {
 // dgrad A operand: idx = (n,hi,wi), k = (r,s,ko) -> dy[n][(hi+pad-r)/st][(wi+pad-s)/st][ko] when divisible & in range
 template <int TILE>
 struct ConvDgradKC {
+  static constexpr bool KC = true;
+  static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
   static constexpr int NV = TILE / 32;
   static constexpr int LD = TILE + 1;  // LDS row stride (floats)
   struct P { const float* dy; ConvGeom g; int rows; int K; };
@@ -193,6 +267,10 @@ struct ConvDgradKC {
       v[j] = ok ? *reinterpret_cast<const float4*>(dy + nbase[j] + ((long)ho * Wo + wo) * Ko + ko) : zero4();
     }
   }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) store2_kc(hi, lo, r0 + j * 32, k4 * 4, v[j]);
+  }
   __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -205,6 +283,9 @@ struct ConvDgradKC {
 // dgrad B operand: k = (r,s,ko), idx = c -> w[ko][r][s][c]   (c contiguous)
 template <int TILE>
 struct ConvFilterMC {
+  static constexpr bool KC = false;
+  static constexpr int LDT = TILE + 32;
+  static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
   static constexpr int NV = TILE / 32;
   static constexpr int LD = TILE + 4;  // LDS row stride (floats)
   static constexpr int VPR = TILE / 4;
@@ -223,6 +304,10 @@ struct ConvFilterMC {
       v[j] = (ok && k < K) ? *reinterpret_cast<const float4*>(base + (long)ko * RSC + (long)tap * C) : zero4();
     }
   }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) store2_mc<LDT>(hi, lo, c4 * 4, kr0 + j * RPP, v[j]);
+  }
   __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j)
@@ -237,6 +322,8 @@ struct S2Taps { int nr, ns; int r[2], s[2]; int dr[2], ds[2]; };  // ho = a + dr
 
 template <int TILE>
 struct ConvDgradS2KC {
+  static constexpr bool KC = true;
+  static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
   static constexpr int NV = TILE / 32;
   static constexpr int LD = TILE + 1;  // LDS row stride (floats)
   struct P { const float* dy; ConvGeom g; S2Taps t; int Hs, Ws; int rows; int K; };
@@ -265,6 +352,10 @@ struct ConvDgradS2KC {
       v[j] = ok ? *reinterpret_cast<const float4*>(dy + nbase[j] + ((long)ho * Wo + wo) * Ko + ko) : zero4();
     }
   }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) store2_kc(hi, lo, r0 + j * 32, k4 * 4, v[j]);
+  }
   __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -276,6 +367,9 @@ struct ConvDgradS2KC {
 
 template <int TILE>
 struct ConvFilterS2MC {
+  static constexpr bool KC = false;
+  static constexpr int LDT = TILE + 32;
+  static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
   static constexpr int NV = TILE / 32;
   static constexpr int LD = TILE + 4;  // LDS row stride (floats)
   static constexpr int VPR = TILE / 4;
@@ -296,6 +390,10 @@ struct ConvFilterS2MC {
       v[j] = (ok && k < K) ? *reinterpret_cast<const float4*>(base + (long)ko * RSC + (long)tap * C) : zero4();
     }
   }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) store2_mc<LDT>(hi, lo, c4 * 4, kr0 + j * RPP, v[j]);
+  }
   __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j)
@@ -308,6 +406,9 @@ struct ConvFilterS2MC {
 // registers and stepped with add/compare instead of being re-derived with integer divisions every K-tile.
 template <int TILE>
 struct ConvIm2colMC {
+  static constexpr bool KC = false;
+  static constexpr int LDT = TILE + 32;
+  static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
   static constexpr int NV = TILE / 32;
   static constexpr int LD = TILE + 4;  // LDS row stride (floats)
   static constexpr int VPR = TILE / 4;
@@ -347,6 +448,10 @@ struct ConvIm2colMC {
     }
     knext = k0 + BK;
   }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) store2_mc<LDT>(hi, lo, c4 * 4, kr0 + j * RPP, v[j]);
+  }
   __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
 #pragma unroll
     for (int j = 0; j < NV; ++j)
@@ -357,6 +462,118 @@ struct ConvIm2colMC {
 // ---------------------------------------------------------------------------------------------------------------
 // Kernel
 // ---------------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------------
+// Epilogue shared by the fp32 and the split-bf16 mainloops (both MFMA shapes have the same 32x32 C/D map).
+// `smem` = at least 4 * 32 * 64 floats of LDS that no wave reads any more.
+// ---------------------------------------------------------------------------------------------------------------
+template <int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const EpiParams& ep, float* smem, int M, int N, int m0,
+                                              int n0, int mt, int z, int wave, int lane) {
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  // Epilogue.  C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), i.e. a
+  // lane owns ONE column — stored straight from the accumulators that is 64 dword stores per lane in 128-B pieces.
+  // Instead each wave transposes its 64x64 sub-tile through the (now free) operand LDS in two 32-row passes and
+  // leaves with 16 B per lane: 16 float4 stores per lane, 256 contiguous bytes per row, and the residual / mask /
+  // GELU' side inputs are read the same way.  This is what the HBM-bound shapes (1x1 convolutions with K = 64) pay for.
+  float* const st = smem + wave * (32 * 64);
+  float* C = ep.C + (long)z * ep.slab_stride;
+  const int c4 = lane & 15, rq = lane >> 4;
+  const int col = n0 + wn * 64 + c4 * 4;
+  float4 bv = zero4();
+  if (ep.bias && col < N) {
+    if (ep.vec) bv = *reinterpret_cast<const float4*>(ep.bias + col);
+    else { bv.x = ep.bias[col]; if (col + 1 < N) bv.y = ep.bias[col + 1]; if (col + 2 < N) bv.z = ep.bias[col + 2]; if (col + 3 < N) bv.w = ep.bias[col + 3]; }
+  }
+  float bs[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float bb1[4] = {0.f, 0.f, 0.f, 0.f}, bb2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ep.bn_part && col < N) {
+    const float4 t1 = *reinterpret_cast<const float4*>(ep.bn_beta + col);
+    bb1[0] = t1.x; bb1[1] = t1.y; bb1[2] = t1.z; bb1[3] = t1.w;
+    if (ep.bn_beta2) { const float4 t2 = *reinterpret_cast<const float4*>(ep.bn_beta2 + col); bb2[0] = t2.x; bb2[1] = t2.y; bb2[2] = t2.z; bb2[3] = t2.w; }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[((e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[i][j][e];
+    __builtin_amdgcn_wave_barrier();  // LDS serves one wave's accesses in issue order; keep the compiler from reordering
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int rl = t * 4 + rq;
+      const int grow = m0 + wm * 64 + i * 32 + rl;
+      float4 v4 = *reinterpret_cast<const float4*>(st + rl * 64 + c4 * 4);
+      if (grow >= M || col >= N) continue;
+      long row = grow;
+      if (ep.rm_on) {
+        const int b_ = grow % ep.rm_Ws; const int q_ = grow / ep.rm_Ws; const int a_ = q_ % ep.rm_Hs; const int n_ = q_ / ep.rm_Hs;
+        row = ((long)n_ * ep.rm_H + 2 * a_ + ep.rm_ph) * ep.rm_W + 2 * b_ + ep.rm_pw;
+      }
+      float v[4] = {ep.alpha * v4.x + bv.x, ep.alpha * v4.y + bv.y, ep.alpha * v4.z + bv.z, ep.alpha * v4.w + bv.w};
+      if ((CXRK_ABL == 5 || CXRK_ABL == 6) && v[0] != 12345.678f) continue;  // ablation: drop the epilogue traffic
+      if (ep.vec) {
+        if (ep.R) { const float4 q = *reinterpret_cast<const float4*>(ep.R + row * ep.ldr + col); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
+        if (ep.C2) *reinterpret_cast<float4*>(ep.C2 + row * ep.ldc2 + col) = make_float4(v[0], v[1], v[2], v[3]);
+        if (ep.act == 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        } else if (ep.act == 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+        }
+        if (ep.auxmode) {
+          const float4 q4 = *reinterpret_cast<const float4*>(ep.aux + row * ep.ldaux + col);
+          const float ax[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = ep.auxmode == 1 ? (ax[q] > 0.f ? v[q] : 0.f) : v[q] * gelu_erf_grad(ax[q]);
+          if (ep.bn_part) {
+            float sb[4] = {0.f, 0.f, 0.f, 0.f};
+            if (ep.bn_sub) { const float4 s4 = *reinterpret_cast<const float4*>(ep.bn_sub + row * ep.bn_ldsub + col); sb[0] = s4.x; sb[1] = s4.y; sb[2] = s4.z; sb[3] = s4.w; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              bs[0][q] += v[q];
+              bs[1][q] += v[q] * (ax[q] - sb[q] - bb1[q]);
+              bs[2][q] += v[q] * (sb[q] - bb2[q]);
+            }
+          }
+        }
+        *reinterpret_cast<float4*>(C + row * ep.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (col + q >= N) break;
+          float x = v[q];
+          if (ep.R) x += ep.R[row * ep.ldr + col + q];
+          if (ep.C2) ep.C2[row * ep.ldc2 + col + q] = x;
+          if (ep.act == 1) x = fmaxf(x, 0.f);
+          else if (ep.act == 2) x = gelu_erf(x);
+          if (ep.auxmode == 1) x = ep.aux[row * ep.ldaux + col + q] > 0.f ? x : 0.f;
+          else if (ep.auxmode == 2) x *= gelu_erf_grad(ep.aux[row * ep.ldaux + col + q]);
+          C[row * ep.ldc + col + q] = x;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (ep.bn_part) {  // add the four row-quads of the wave (lanes c4, c4+16, c4+32, c4+48), lanes 0..15 write
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t = bs[k][q];
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        bs[k][q] = t;
+      }
+    if (rq == 0 && col < N) {
+      float* dst = ep.bn_part + ((long)(mt * WM + wm) * 3) * N + col;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) *reinterpret_cast<float4*>(dst + (long)k * N) = make_float4(bs[k][0], bs[k][1], bs[k][2], bs[k][3]);
+    }
+  }
+}
+
 #ifndef CXRK_OCC
 #define CXRK_OCC 3
 #endif
@@ -458,115 +675,108 @@ __global__ __launch_bounds__(NTHREADS, CXRK_OCC) void gemm_f32_kernel(typename L
     if (NBUF == 2) cur ^= 1;
   }
 
-  // Epilogue.  C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), i.e. a
-  // lane owns ONE column — stored straight from the accumulators that is 64 dword stores per lane in 128-B pieces.
-  // Instead each wave transposes its 64x64 sub-tile through the (now free) operand LDS in two 32-row passes and
-  // leaves with 16 B per lane: 16 float4 stores per lane, 256 contiguous bytes per row, and the residual / mask /
-  // GELU' side inputs are read the same way.  This is what the HBM-bound shapes (1x1 convolutions with K = 64) pay for.
   static_assert(BK * (LDA + LDB) >= 4 * 32 * 64, "operand LDS too small to stage the epilogue");
   __syncthreads();  // every wave is done reading operand tiles
-  float* const st = smem + wave * (32 * 64);
-  float* C = ep.C + (long)z * ep.slab_stride;
-  const int c4 = lane & 15, rq = lane >> 4;
-  const int col = n0 + wn * 64 + c4 * 4;
-  float4 bv = zero4();
-  if (ep.bias && col < N) {
-    if (ep.vec) bv = *reinterpret_cast<const float4*>(ep.bias + col);
-    else { bv.x = ep.bias[col]; if (col + 1 < N) bv.y = ep.bias[col + 1]; if (col + 2 < N) bv.z = ep.bias[col + 2]; if (col + 3 < N) bv.w = ep.bias[col + 3]; }
-  }
-  float bs[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  float bb1[4] = {0.f, 0.f, 0.f, 0.f}, bb2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (ep.bn_part && col < N) {
-    const float4 t1 = *reinterpret_cast<const float4*>(ep.bn_beta + col);
-    bb1[0] = t1.x; bb1[1] = t1.y; bb1[2] = t1.z; bb1[3] = t1.w;
-    if (ep.bn_beta2) { const float4 t2 = *reinterpret_cast<const float4*>(ep.bn_beta2 + col); bb2[0] = t2.x; bb2[1] = t2.y; bb2[2] = t2.z; bb2[3] = t2.w; }
-  }
+  gemm_epilogue<WM, WN>(acc, ep, smem, M, N, m0, n0, mt, z, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-bf16 mainloop: same tiling, loaders, remap and epilogue as gemm_f32_kernel; the operand tiles are split into
+// bf16 hi/lo planes while they are staged into LDS ([idx][k], 80-byte rows) and each 32x32x16 product costs three
+// v_mfma_f32_32x32x16_bf16 (96 cycles) instead of eight v_mfma_f32_32x32x2_f32 (512 cycles).
+// ---------------------------------------------------------------------------------------------------------------
+template <class LA, class LB, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS, 3) void gemm_x3_kernel(typename LA::P pa, typename LB::P pb, EpiParams ep,
+                                                              int M, int N, int K, int nMt, int nNt, int kchunk) {
+  constexpr int BM = WM * 64, BN = WN * 64;
+  constexpr int PLANE_A = LA::PLANE, PLANE_B = LB::PLANE;  // halfwords
+  static_assert(2 * (PLANE_A + PLANE_B) * 2 >= 4 * 32 * 64 * 4, "operand LDS too small to stage the epilogue");
+  __shared__ __attribute__((aligned(16))) unsigned short smem16[2 * (PLANE_A + PLANE_B)];
+  unsigned short* const Ahi = smem16;
+  unsigned short* const Alo = Ahi + PLANE_A;
+  unsigned short* const Bhi = Alo + PLANE_A;
+  unsigned short* const Blo = Bhi + PLANE_B;
+
+  const int nwg = nMt * nNt;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, idx = b >> 3;
+  const int qq = nwg >> 3, rr = nwg & 7;
+  const int wgid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+  const int mt = wgid / nNt;
+  const int nt = wgid - mt * nNt;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int z = blockIdx.y;
+  const int kbeg = z * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+
+  LA la; LB lb;
+  la.init(pa, m0, tid);
+  lb.init(pb, n0, tid);
+
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) st[((e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[i][j][e];
-    __builtin_amdgcn_wave_barrier();  // LDS serves one wave's accesses in issue order; keep the compiler from reordering
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int rl = t * 4 + rq;
-      const int grow = m0 + wm * 64 + i * 32 + rl;
-      float4 v4 = *reinterpret_cast<const float4*>(st + rl * 64 + c4 * 4);
-      if (grow >= M || col >= N) continue;
-      long row = grow;
-      if (ep.rm_on) {
-        const int b_ = grow % ep.rm_Ws; const int q_ = grow / ep.rm_Ws; const int a_ = q_ % ep.rm_Hs; const int n_ = q_ / ep.rm_Hs;
-        row = ((long)n_ * ep.rm_H + 2 * a_ + ep.rm_ph) * ep.rm_W + 2 * b_ + ep.rm_pw;
-      }
-      float v[4] = {ep.alpha * v4.x + bv.x, ep.alpha * v4.y + bv.y, ep.alpha * v4.z + bv.z, ep.alpha * v4.w + bv.w};
-      if ((CXRK_ABL == 5 || CXRK_ABL == 6) && v[0] != 12345.678f) continue;  // ablation: drop the epilogue traffic
-      if (ep.vec) {
-        if (ep.R) { const float4 q = *reinterpret_cast<const float4*>(ep.R + row * ep.ldr + col); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
-        if (ep.C2) *reinterpret_cast<float4*>(ep.C2 + row * ep.ldc2 + col) = make_float4(v[0], v[1], v[2], v[3]);
-        if (ep.act == 1) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-        } else if (ep.act == 2) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
-        }
-        if (ep.auxmode) {
-          const float4 q4 = *reinterpret_cast<const float4*>(ep.aux + row * ep.ldaux + col);
-          const float ax[4] = {q4.x, q4.y, q4.z, q4.w};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = ep.auxmode == 1 ? (ax[q] > 0.f ? v[q] : 0.f) : v[q] * gelu_erf_grad(ax[q]);
-          if (ep.bn_part) {
-            float sb[4] = {0.f, 0.f, 0.f, 0.f};
-            if (ep.bn_sub) { const float4 s4 = *reinterpret_cast<const float4*>(ep.bn_sub + row * ep.bn_ldsub + col); sb[0] = s4.x; sb[1] = s4.y; sb[2] = s4.z; sb[3] = s4.w; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              bs[0][q] += v[q];
-              bs[1][q] += v[q] * (ax[q] - sb[q] - bb1[q]);
-              bs[2][q] += v[q] * (sb[q] - bb2[q]);
-            }
-          }
-        }
-        *reinterpret_cast<float4*>(C + row * ep.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (col + q >= N) break;
-          float x = v[q];
-          if (ep.R) x += ep.R[row * ep.ldr + col + q];
-          if (ep.C2) ep.C2[row * ep.ldc2 + col + q] = x;
-          if (ep.act == 1) x = fmaxf(x, 0.f);
-          else if (ep.act == 2) x = gelu_erf(x);
-          if (ep.auxmode == 1) x = ep.aux[row * ep.ldaux + col + q] > 0.f ? x : 0.f;
-          else if (ep.auxmode == 2) x *= gelu_erf_grad(ep.aux[row * ep.ldaux + col + q]);
-          C[row * ep.ldc + col + q] = x;
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float4 ra[LA::NV], rb[LB::NV];
+  if (kbeg < kend) {
+    la.load(kbeg, ra); lb.load(kbeg, rb);
+    la.store2(Ahi, Alo, ra); lb.store2(Bhi, Blo, rb);
   }
-  if (ep.bn_part) {  // add the four row-quads of the wave (lanes c4, c4+16, c4+32, c4+48), lanes 0..15 write
+  __syncthreads();
+  if (kbeg + BK < kend) { la.load(kbeg + BK, ra); lb.load(kbeg + BK, rb); }
+
+  // lane (r, h) of v_mfma_f32_32x32x16_bf16 holds A[row r][k = 8h..8h+7] and B[k = 8h..8h+7][col r]
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int kc = 0; kc < BK / 16; ++kc) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float t = bs[k][q];
-        t += __shfl_xor(t, 16, 64);
-        t += __shfl_xor(t, 32, 64);
-        bs[k][q] = t;
+      for (int i = 0; i < 2; ++i) {
+        if constexpr (LA::KC) {
+          ah[i] = frag_kc(Ahi, wm * 64 + i * 32, kc, lane); al[i] = frag_kc(Alo, wm * 64 + i * 32, kc, lane);
+        } else {
+          ah[i] = frag_mc<LA::LDT>(Ahi, wm * 64 + i * 32, kc, lane); al[i] = frag_mc<LA::LDT>(Alo, wm * 64 + i * 32, kc, lane);
+        }
+        if constexpr (LB::KC) {
+          bh[i] = frag_kc(Bhi, wn * 64 + i * 32, kc, lane); bl[i] = frag_kc(Blo, wn * 64 + i * 32, kc, lane);
+        } else {
+          bh[i] = frag_mc<LB::LDT>(Bhi, wn * 64 + i * 32, kc, lane); bl[i] = frag_mc<LB::LDT>(Blo, wn * 64 + i * 32, kc, lane);
+        }
       }
-    if (rq == 0 && col < N) {
-      float* dst = ep.bn_part + ((long)(mt * WM + wm) * 3) * N + col;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) *reinterpret_cast<float4*>(dst + (long)k * N) = make_float4(bs[k][0], bs[k][1], bs[k][2], bs[k][3]);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
     }
+    __syncthreads();  // everyone is done reading before the single buffer is overwritten
+    if (k0 + BK < kend) { la.store2(Ahi, Alo, ra); lb.store2(Bhi, Blo, rb); }
+    __syncthreads();
+    if (k0 + 2 * BK < kend) { la.load(k0 + 2 * BK, ra); lb.load(k0 + 2 * BK, rb); }
   }
+  __syncthreads();
+  gemm_epilogue<WM, WN>(acc, ep, reinterpret_cast<float*>(smem16), M, N, m0, n0, mt, z, wave, lane);
 }
+
+// 0 = exact fp32 MFMA (default), 1 = split-bf16.  Process-wide, set through cxrk_set_precision().
+inline int& gemm_precision_mode() { static int mode = 0; return mode; }
 
 // Host launcher.  splitk > 1 writes plain partial slabs (caller reduces them).
 template <class LA, class LB, int WM, int WN>
 static int launch_gemm(const typename LA::P& pa, const typename LB::P& pb, const EpiParams& ep, int M, int N, int K,
-                       int splitk, hipStream_t stream) {
+                       int splitk, hipStream_t stream, bool force_fp32 = false) {
   constexpr int BM = WM * 64, BN = WN * 64;
   if (M <= 0 || N <= 0 || K <= 0) return CXRK_ERR_ARG;
   const int nMt = ceil_div(M, BM), nNt = ceil_div(N, BN);
@@ -578,7 +788,13 @@ static int launch_gemm(const typename LA::P& pa, const typename LB::P& pb, const
   auto ok16 = [](const void* p_, long ld) { return p_ == nullptr || (aligned16(p_) && (ld % 4) == 0); };
   e.vec = (N % 4 == 0) && ok16(e.C, e.ldc) && ((e.slab_stride % 4) == 0) && ok16(e.R, e.ldr) && ok16(e.aux, e.ldaux) &&
           ok16(e.C2, e.ldc2) && (e.bias == nullptr || aligned16(e.bias));
-  hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
+  // split-bf16 only where it pays and is well conditioned: small problems (adapters, heads: < 1 GFLOP) and launches the
+  // caller marks exact (the stem convolution: an all-positive input makes its weight gradient a cancelling sum) stay fp32
+  const bool split = gemm_precision_mode() == 1 && !force_fp32 && 2.0 * M * N * (double)K >= 1073741824.0;
+  if (split)
+    hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
   CXRK_LAUNCH_CHECK();
   return splitk;  // >= 1: number of slabs actually written
 }

@@ -16,6 +16,13 @@ from incremental_multimodal_medical_learning_ii_amd.models import myLinearModel,
 
 DEV = "cuda"
 TOL = 1e-3
+from incremental_multimodal_medical_learning_ii_amd import _lib as _cxr_lib  # noqa: E402
+
+
+def _flip_budget():
+    """(max flipped ReLU decisions, max |pre-activation| / layer max at a flip): exact fp32 forward differs from the
+    oracle in the last bit only; the split-bf16 contraction (CXRK_PRECISION=split_bf16) by ~1e-5."""
+    return (20000, 2e-3) if _cxr_lib.get_precision() == "split_bf16" else (20, 1e-5)
 
 
 def rel(a, b):
@@ -139,7 +146,7 @@ def test_image_model_forward_backward(golden_dir):
     named = dict(model.named_parameters())
     # (1) rigorous gradient parity: oracle run under the same ReLU decisions -> every tensor within 1e-3
     _, gref, pol = _image_oracle_with_decisions(sd_cpu, x, probe, masks)
-    assert pol.count > 5_000_000 and pol.flips <= 20 and pol.max_flip_rel < 1e-5, (pol.flips, pol.max_flip_rel)
+    assert pol.count > 5_000_000 and pol.flips <= _flip_budget()[0] and pol.max_flip_rel < _flip_budget()[1], (pol.flips, pol.max_flip_rel)
     worst = max(((rel(named[k].grad, v), k) for k, v in gref.items()), key=lambda t: t[0])
     assert worst[0] < TOL, worst
     # (2) against the committed fixture (oracle's own decisions): a kink flip moves upstream gradients by ~1e-3,
@@ -147,8 +154,9 @@ def test_image_model_forward_backward(golden_dir):
     errs = {k[7:]: abs(named[k[7:]].grad.double().norm().item() - float(g[k])) / max(float(g[k]), 1e-30)
             for k in g.files if k.startswith("gnorm::") and "fc." not in k}
     assert max(errs.values()) < 3e-2, max(errs.items(), key=lambda t: t[1])
-    assert errs["projector.model.3.weight"] < 1e-5 and errs["encoder.encoder.layer4.2.conv3.weight"] < 1e-4
-    assert rel(named["projector.model.3.bias"].grad, g["g::projector.model.3.bias"]) < 1e-5
+    if _cxr_lib.get_precision() == "fp32":
+        assert errs["projector.model.3.weight"] < 1e-5 and errs["encoder.encoder.layer4.2.conv3.weight"] < 1e-4
+    assert rel(named["projector.model.3.bias"].grad, g["g::projector.model.3.bias"]) < (1e-5 if _cxr_lib.get_precision() == "fp32" else 1e-3)
     # projector pinned against the reference's modules.MLP: patch embeddings API
     with torch.no_grad():
         patches = model.get_patchwise_projected_embeddings(x.to(DEV), normalize=True)
@@ -199,7 +207,7 @@ def test_adapter_step_vs_reference_models(golden_dir):
             for k in g.files:
                 if k.startswith(f"w{step}::"):
                     mod, name = (img_ad, k.split("image_adapter.")[1]) if "image_adapter" in k else (txt_ad, k.split("text_adapter.")[1])
-                    assert rel(mod.state_dict()[name], g[k]) < 1e-5, k
+                    assert rel(mod.state_dict()[name], g[k]) < 1e-5, k   # adapter GEMMs are < 1 GFLOP: exact fp32 in every mode
     lin = myLinearModel()
     syn.fill_module_(lin, "dense_adapter.")
     assert rel(lin.to(DEV)(embs), g["dense_out"]) < TOL
@@ -259,7 +267,7 @@ def test_joint_step_vs_cpu_oracle():
     opt = torch.optim.Adam(leaves, lr=1e-4)
     pol = ref_image.ReluPolicy(masks)
     loss_ref = ref_step.joint_step(ip, tp, images, ids, mask, tau, opt, n_layers=2, n_heads=2, relu=pol)
-    assert pol.flips <= 5 and pol.max_flip_rel < 1e-5
+    assert pol.flips <= max(5, _flip_budget()[0] // 100) and pol.max_flip_rel < _flip_budget()[1]
     assert abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()) < TOL, (loss.item(), loss_ref.item())
     worst = ("", 0.0)
     for (side, n), gdev in grads_dev.items():
@@ -271,10 +279,11 @@ def test_joint_step_vs_cpu_oracle():
             worst = (n, e)
     assert worst[1] < TOL, worst
     isd, tsd = im.state_dict(), tm.state_dict()
+    ptol = TOL if _cxr_lib.get_precision() == "fp32" else 3e-3   # Adam's first step is ~lr*sign(g): entries with g ~ 0 amplify
     for d, sd in ((ip, isd), (tp, tsd)):
         for k, v in d.items():
             if v.requires_grad:
-                assert rel(sd[k], v) < TOL, k
+                assert rel(sd[k], v) < ptol, k
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE config 1
