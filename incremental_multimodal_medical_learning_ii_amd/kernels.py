@@ -84,6 +84,12 @@ def _tile(M: int, N: int) -> str:
     return "4,1" if N <= 64 else ("1,4" if M <= 64 else "2,2")
 
 
+def _kern(flops: float, exact: bool = False) -> str:
+    """Name of the mainloop a launch runs (mirrors launch_gemm's policy in csrc/gemm_core.h)."""
+    split = _lib.get_precision() == "split_bf16" and not exact and flops >= 1073741824.0
+    return "gemm_x3_kernel" if split else "gemm_f32_kernel"
+
+
 class _Workspace:
     """Grow-on-demand scratch buffer per device; reuse is safe because all kernels run stream-ordered."""
 
@@ -139,7 +145,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K:
         wsb = lib.cxrk_gemm_splitk_ws_bytes(M, N, splitk)
         ws = workspace(wsb, out.device)
         wsb = ws.numel() * 4
-    ev = profiler.bracket(f"gemm_f32_kernel<Dense{'MC' if trans_a else 'KC'},Dense{'KC' if trans_b else 'MC'},{_tile(M, N)}>",
+    ev = profiler.bracket(f"{_kern(2.0 * M * N * K)}<Dense{'MC' if trans_a else 'KC'},Dense{'KC' if trans_b else 'MC'},{_tile(M, N)}>",
                           2.0 * M * N * K) if profiler.on else None
     rc = lib.cxrk_gemm_f32(int(trans_a), int(trans_b), M, N, K, _p(a), lda, _p(b), ldb, _p(out), ldc, _p(bias),
                            _p(residual), ldr, _p(aux), ldaux, auxmode, _p(preact_out), ldc2, act, float(alpha),
@@ -217,8 +223,8 @@ def conv_fwd(x, w_scaled, shift, residual, y, N, H, W, C, Ko, R, S, stride, pad,
     ev = None
     if profiler.on:
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
-        ev = profiler.bracket(f"gemm_f32_kernel<ConvIm2colKC,DenseKC,{'4,1' if Ko <= 64 else '2,2'}>",
-                              2.0 * N * Ho * Wo * Ko * R * S * C)
+        fl = 2.0 * N * Ho * Wo * Ko * R * S * C
+        ev = profiler.bracket(f"{_kern(fl, C <= 4)}<ConvIm2colKC,DenseKC,{'4,1' if Ko <= 64 else '2,2'}>", fl)
     rc = lib.cxrk_conv_bn_act_fwd(_p(_chk(x, "conv.x")), _p(w_scaled), _p(shift), _p(residual), _p(y), N, H, W, C, Ko,
                                   R, S, stride, pad, int(relu), _stream())
     if ev is not None:
@@ -232,8 +238,8 @@ def conv_bwd_data(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R, S, st
     ev = None
     if profiler.on:  # algorithmic FLOPs of a data gradient = those of the forward conv (stride-2 zero taps are waste)
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
-        ev = profiler.bracket(f"gemm_f32_kernel<ConvDgradKC,ConvFilterMC,{'4,1' if C <= 64 else '2,2'}>",
-                              2.0 * N * Ho * Wo * Ko * R * S * C)
+        fl = 2.0 * N * Ho * Wo * Ko * R * S * C
+        ev = profiler.bracket(f"{_kern(fl)}<ConvDgradKC,ConvFilterMC,{'4,1' if C <= 64 else '2,2'}>", fl)
     rc = lib.cxrk_conv_bn_act_bwd_data(_p(_chk(dy, "conv.dy")), _p(w_scaled), _p(residual), _p(relu_src), _p(dx), N, H,
                                        W, C, Ko, R, S, stride, pad, _stream())
     if ev is not None:
@@ -259,8 +265,8 @@ def conv_bwd_data_bnsum(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R,
     ev = None
     if profiler.on:
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
-        ev = profiler.bracket(f"gemm_f32_kernel<ConvDgradKC,ConvFilterMC,{'4,1' if C <= 64 else '2,2'}>",
-                              2.0 * N * Ho * Wo * Ko * R * S * C)
+        fl = 2.0 * N * Ho * Wo * Ko * R * S * C
+        ev = profiler.bracket(f"{_kern(fl)}<ConvDgradKC,ConvFilterMC,{'4,1' if C <= 64 else '2,2'}>", fl)
     rc = lib.cxrk_conv_bn_act_bwd_data_bnsum(_p(_chk(dy, "conv.dy")), _p(w_scaled), _p(residual), _p(relu_src), _p(dx), N, H, W, C,
                                              Ko, R, S, stride, pad, _p(bn_sub), _p(bn_beta), _p(bn_beta2), _p(sums), _p(ws),
                                              ws.numel() * 4, _stream())
@@ -278,8 +284,8 @@ def conv_bwd_params(x, dy, w, scale, rstd, rmean, sumdy, gamma, sumdyy, dw, dgam
     ev = None
     if profiler.on:
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
-        ev = profiler.bracket(f"gemm_f32_kernel<DenseMC,ConvIm2colMC,{'1,4' if Ko <= 64 else '2,2'}>",
-                              2.0 * N * Ho * Wo * Ko * R * S * Cpad)
+        fl = 2.0 * N * Ho * Wo * Ko * R * S * Cpad
+        ev = profiler.bracket(f"{_kern(fl, Cpad <= 4)}<DenseMC,ConvIm2colMC,{'1,4' if Ko <= 64 else '2,2'}>", fl)
     check(lib.cxrk_conv_bn_act_bwd_params(_p(_chk(x, "conv.x")), _p(_chk(dy, "conv.dy")), _p(w), _p(scale), _p(rstd),
                                           _p(rmean), _p(sumdy), _p(gamma), _p(sumdyy), _p(dw), _p(dgamma), _p(dbeta),
                                           int(accumulate), N, H, W,
