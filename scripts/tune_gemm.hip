@@ -15,6 +15,9 @@ int main(int argc, char** argv) {
   hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice);
   hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
   EpiParams ep{}; ep.C = C; ep.ldc = N; ep.alpha = 1.f;
+#ifdef CXRK_TUNE_SPLIT
+  gemm_precision_mode() = 1;
+#endif
   DenseKC<128>::P pa{A, K, M, K}; DenseKC<128>::P pb{B, K, N, K};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) launch_gemm<DenseKC<128>, DenseKC<128>, 2, 2>(pa, pb, ep, M, N, K, 1, 0);
