@@ -575,7 +575,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const EpiPara
 }
 
 #ifndef CXRK_OCC
-#define CXRK_OCC 3
+#define CXRK_OCC ((WM == 2 && WN == 2) ? 3 : 2)  // the 256x64 / 64x256 tiles stage more registers: at 3 waves/SIMD they spill
 #endif
 template <class LA, class LB, int WM, int WN>
 __global__ __launch_bounds__(NTHREADS, CXRK_OCC) void gemm_f32_kernel(typename LA::P pa, typename LB::P pb, EpiParams ep,
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(NTHREADS, CXRK_OCC) void gemm_f32_kernel(typename L
 // v_mfma_f32_32x32x16_bf16 (96 cycles) instead of eight v_mfma_f32_32x32x2_f32 (512 cycles).
 // ---------------------------------------------------------------------------------------------------------------
 template <class LA, class LB, int WM, int WN>
-__global__ __launch_bounds__(NTHREADS, 3) void gemm_x3_kernel(typename LA::P pa, typename LB::P pb, EpiParams ep,
+__global__ __launch_bounds__(NTHREADS, (WM == 2 && WN == 2) ? 3 : 2) void gemm_x3_kernel(typename LA::P pa, typename LB::P pb, EpiParams ep,
                                                               int M, int N, int K, int nMt, int nNt, int kchunk) {
   constexpr int BM = WM * 64, BN = WN * 64;
   constexpr int PLANE_A = LA::PLANE, PLANE_B = LB::PLANE;  // halfwords
