@@ -307,12 +307,23 @@ extern "C" int cxrk_conv_bn_act_fwd(const float* x, const float* w_scaled, const
   EpiParams ep{};
   ep.C = y; ep.ldc = Ko; ep.bias = shift; ep.R = residual; ep.ldr = Ko; ep.act = relu ? 1 : 0; ep.alpha = 1.f;
   int rc;
-  if (Ko <= 64) {
-    ConvIm2colKC<256>::P pa{x, g, M, K}; DenseKC<64>::P pb{w_scaled, (long)K, Ko, K};
-    rc = launch_gemm<ConvIm2colKC<256>, DenseKC<64>, 4, 1>(pa, pb, ep, M, Ko, K, 1, stream, C <= 4);
+  const bool tapwise = (C % BK == 0) && R * S <= 32;  // a K-tile inside one filter tap (everything but the stem)
+  if (tapwise) {
+    if (Ko <= 64) {
+      ConvIm2colKC<256>::P pa{x, g, M, K}; DenseKC<64>::P pb{w_scaled, (long)K, Ko, K};
+      rc = launch_gemm<ConvIm2colKC<256>, DenseKC<64>, 4, 1>(pa, pb, ep, M, Ko, K, 1, stream);
+    } else {
+      ConvIm2colKC<128>::P pa{x, g, M, K}; DenseKC<128>::P pb{w_scaled, (long)K, Ko, K};
+      rc = launch_gemm<ConvIm2colKC<128>, DenseKC<128>, 2, 2>(pa, pb, ep, M, Ko, K, 1, stream);
+    }
   } else {
-    ConvIm2colKC<128>::P pa{x, g, M, K}; DenseKC<128>::P pb{w_scaled, (long)K, Ko, K};
-    rc = launch_gemm<ConvIm2colKC<128>, DenseKC<128>, 2, 2>(pa, pb, ep, M, Ko, K, 1, stream, C <= 4);
+    if (Ko <= 64) {
+      ConvIm2colKC<256, false>::P pa{x, g, M, K}; DenseKC<64>::P pb{w_scaled, (long)K, Ko, K};
+      rc = launch_gemm<ConvIm2colKC<256, false>, DenseKC<64>, 4, 1>(pa, pb, ep, M, Ko, K, 1, stream, C <= 4);
+    } else {
+      ConvIm2colKC<128, false>::P pa{x, g, M, K}; DenseKC<128>::P pb{w_scaled, (long)K, Ko, K};
+      rc = launch_gemm<ConvIm2colKC<128, false>, DenseKC<128>, 2, 2>(pa, pb, ep, M, Ko, K, 1, stream, C <= 4);
+    }
   }
   return rc < 0 ? rc : CXRK_OK;
 }
@@ -334,6 +345,7 @@ static int conv_bwd_data_impl(const float* dy, const float* w_scaled, const floa
                               const float* bn_sub, const float* bn_beta, const float* bn_beta2, hipStream_t stream) {
   CXRK_CHECK_ARG(dy && w_scaled && dx && N > 0 && C % 4 == 0 && Ko % 4 == 0 && aligned16(dy) && aligned16(w_scaled));
   CXRK_CHECK_ARG(stride == 1 || stride == 2);
+  if (Ko % BK != 0 || R * S > 32) return CXRK_ERR_UNSUPPORTED;  // the gather keeps a K-tile inside one filter tap
   const ConvGeom g = make_geom(N, H, W, C, Ko, R, S, stride, pad);
   const long Ml = (long)N * H * W;
   CXRK_CHECK_ARG(Ml < (1L << 31));

@@ -55,12 +55,22 @@ constexpr int LDH = BK + 8;  // LDS row stride of a bf16 operand tile, in halfwo
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+// 5 vector instructions per pair: v_cvt_pk_bf16_f32 (hi, round-to-nearest-even), shift / mask back to f32, one packed
+// subtract, v_cvt_pk_bf16_f32 (lo).  The first conversion is inline asm so that the compiler keeps the packed result
+// instead of converting each element a second time on its own.
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  unsigned hp;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hp) : "v"(x0), "v"(x1));
+  const f32x2 x = {x0, x1};
+  const f32x2 hf = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xffff0000u)};
+  const f32x2 l = x - hf;
+  const bf16x2 lb = {(__bf16)l[0], (__bf16)l[1]};
+  hi = hp; lo = __builtin_bit_cast(unsigned, lb);
+}
 __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
-  const bf16x2 h01 = {(__bf16)v.x, (__bf16)v.y}, h23 = {(__bf16)v.z, (__bf16)v.w};
-  const float r0 = v.x - (float)h01[0], r1 = v.y - (float)h01[1], r2 = v.z - (float)h23[0], r3 = v.w - (float)h23[1];
-  const bf16x2 l01 = {(__bf16)r0, (__bf16)r1}, l23 = {(__bf16)r2, (__bf16)r3};
-  hi.x = __builtin_bit_cast(unsigned, h01); hi.y = __builtin_bit_cast(unsigned, h23);
-  lo.x = __builtin_bit_cast(unsigned, l01); lo.y = __builtin_bit_cast(unsigned, l23);
+  split2(v.x, v.y, hi.x, lo.x);
+  split2(v.z, v.w, hi.y, lo.y);
 }
 // K-contiguous operand: 4 consecutive k of one row -> one 8-byte store per plane
 __device__ __forceinline__ void store2_kc(unsigned short* hi, unsigned short* lo, int row, int k, const float4& v) {
@@ -101,363 +111,9 @@ __device__ __forceinline__ bf16x8 frag_mc(const unsigned short* plane, int row0,
   return __builtin_bit_cast(bf16x8, x);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Loaders.  TILE = extent of the idx dimension in the block tile.  Every loader exposes
-//   P (host-filled parameters), init(P, idx0, tid), load(k0, v[NV]), store(S, v[NV]).
-// ---------------------------------------------------------------------------------------------------------------
-
-// X(idx, k) = ptr[idx*ld + k]   (k contiguous)
-template <int TILE>
-struct DenseKC {
-  static constexpr bool KC = true;
-  static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
-  static constexpr int LD = TILE + 1;  // LDS row stride (floats)
-  struct P { const float* ptr; long ld; int rows; int K; };
-  const float* rp[NV];
-  int k4, r0, K;
-  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
-    k4 = tid & 7; r0 = tid >> 3; K = p.K;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int row = idx0 + r0 + j * 32;
-      rp[j] = row < p.rows ? p.ptr + (long)row * p.ld : nullptr;
-    }
-  }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
-    const int k = k0 + k4 * 4;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = (rp[j] != nullptr && k < K) ? *reinterpret_cast<const float4*>(rp[j] + k) : zero4();
-  }
-  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) store2_kc(hi, lo, r0 + j * 32, k4 * 4, v[j]);
-  }
-  __device__ __forceinline__ void store(float* S, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      float* d = S + (k4 * 4) * LD + r0 + j * 32;
-      d[0] = v[j].x; d[LD] = v[j].y; d[2 * LD] = v[j].z; d[3 * LD] = v[j].w;
-    }
-  }
-};
-
-// X(idx, k) = ptr[k*ld + idx]   (idx contiguous)
-template <int TILE>
-struct DenseMC {
-  static constexpr bool KC = false;
-  static constexpr int LDT = TILE + 32;
-  static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
-  static constexpr int LD = TILE + 4;  // LDS row stride (floats)
-  static constexpr int VPR = TILE / 4;          // float4 per k-row
-  static constexpr int RPP = NTHREADS / VPR;    // k-rows per pass
-  struct P { const float* ptr; long ld; int cols; int K; };
-  const float* base; long ld_;
-  int c4, kr0, K; bool ok;
-  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
-    c4 = tid % VPR; kr0 = tid / VPR; K = p.K; ld_ = p.ld;
-    ok = idx0 + c4 * 4 < p.cols;
-    base = p.ptr + idx0 + c4 * 4;
-  }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int k = k0 + kr0 + j * RPP;
-      v[j] = (ok && k < K) ? *reinterpret_cast<const float4*>(base + (long)k * ld_) : zero4();
-    }
-  }
-  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) store2_mc<LDT>(hi, lo, c4 * 4, kr0 + j * RPP, v[j]);
-  }
-  __device__ __forceinline__ void store(float* S, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-      *reinterpret_cast<float4*>(S + (kr0 + j * RPP) * LD + c4 * 4) = v[j];
-  }
-};
-
-// NHWC geometry shared by the convolution gathers.
-struct ConvGeom {
-  int N, H, W, C;        // input  x[N][H][W][C]
-  int Ho, Wo, Ko;        // output y[N][Ho][Wo][Ko]
-  int R, S, stride, pad; // filter w[Ko][R][S][C]
-};
-
-// fprop A operand: idx = (n,ho,wo), k = (r,s,c) -> x[n][ho*st-pad+r][wo*st-pad+s][c]   (c contiguous)
-template <int TILE>
-struct ConvIm2colKC {
-  static constexpr bool KC = true;
-  static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
-  static constexpr int LD = TILE + 1;  // LDS row stride (floats)
-  struct P { const float* x; ConvGeom g; int rows; int K; };
-  long off[NV]; int hi0[NV], wi0[NV];
-  const float* x; int k4, r0, K, H, W, C, S;
-  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
-    k4 = tid & 7; r0 = tid >> 3; K = p.K; x = p.x; H = p.g.H; W = p.g.W; C = p.g.C; S = p.g.S;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int row = idx0 + r0 + j * 32;
-      if (row < p.rows) {
-        const int wo = row % p.g.Wo; const int t = row / p.g.Wo; const int ho = t % p.g.Ho; const int n = t / p.g.Ho;
-        hi0[j] = ho * p.g.stride - p.g.pad; wi0[j] = wo * p.g.stride - p.g.pad;
-        off[j] = (((long)n * H + hi0[j]) * W + wi0[j]) * C;
-      } else { hi0[j] = -(1 << 28); wi0[j] = 0; off[j] = 0; }
-    }
-  }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
-    const int k = k0 + k4 * 4;
-    const int tap = k / C, c = k - tap * C;
-    const int r = tap / S, s = tap - r * S;
-    const long toff = ((long)r * W + s) * C + c;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int hi = hi0[j] + r, wi = wi0[j] + s;
-      const bool ok = (k < K) && ((unsigned)hi < (unsigned)H) && ((unsigned)wi < (unsigned)W);
-      v[j] = ok ? *reinterpret_cast<const float4*>(x + off[j] + toff) : zero4();
-    }
-  }
-  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) store2_kc(hi, lo, r0 + j * 32, k4 * 4, v[j]);
-  }
-  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      float* d = Sm + (k4 * 4) * LD + r0 + j * 32;
-      d[0] = v[j].x; d[LD] = v[j].y; d[2 * LD] = v[j].z; d[3 * LD] = v[j].w;
-    }
-  }
-};
-
-// dgrad A operand: idx = (n,hi,wi), k = (r,s,ko) -> dy[n][(hi+pad-r)/st][(wi+pad-s)/st][ko] when divisible & in range
-template <int TILE>
-struct ConvDgradKC {
-  static constexpr bool KC = true;
-  static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
-  static constexpr int LD = TILE + 1;  // LDS row stride (floats)
-  struct P { const float* dy; ConvGeom g; int rows; int K; };
-  long nbase[NV]; int hp[NV], wp[NV];
-  const float* dy; int k4, r0, K, Ho, Wo, Ko, S, st;
-  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
-    k4 = tid & 7; r0 = tid >> 3; K = p.K; dy = p.dy; Ho = p.g.Ho; Wo = p.g.Wo; Ko = p.g.Ko; S = p.g.S; st = p.g.stride;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int row = idx0 + r0 + j * 32;
-      if (row < p.rows) {
-        const int wi = row % p.g.W; const int t = row / p.g.W; const int hi = t % p.g.H; const int n = t / p.g.H;
-        hp[j] = hi + p.g.pad; wp[j] = wi + p.g.pad; nbase[j] = (long)n * Ho * Wo * Ko;
-      } else { hp[j] = -(1 << 28); wp[j] = 0; nbase[j] = 0; }
-    }
-  }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
-    const int k = k0 + k4 * 4;
-    const int tap = k / Ko, ko = k - tap * Ko;
-    const int r = tap / S, s = tap - r * S;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int hn = hp[j] - r, wn = wp[j] - s;
-      bool ok = (k < K) && hn >= 0 && wn >= 0;
-      int ho = hn, wo = wn;
-      if (st == 2) { ok = ok && ((hn & 1) == 0) && ((wn & 1) == 0); ho = hn >> 1; wo = wn >> 1; }
-      ok = ok && ho < Ho && wo < Wo;
-      v[j] = ok ? *reinterpret_cast<const float4*>(dy + nbase[j] + ((long)ho * Wo + wo) * Ko + ko) : zero4();
-    }
-  }
-  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) store2_kc(hi, lo, r0 + j * 32, k4 * 4, v[j]);
-  }
-  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      float* d = Sm + (k4 * 4) * LD + r0 + j * 32;
-      d[0] = v[j].x; d[LD] = v[j].y; d[2 * LD] = v[j].z; d[3 * LD] = v[j].w;
-    }
-  }
-};
-
-// dgrad B operand: k = (r,s,ko), idx = c -> w[ko][r][s][c]   (c contiguous)
-template <int TILE>
-struct ConvFilterMC {
-  static constexpr bool KC = false;
-  static constexpr int LDT = TILE + 32;
-  static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
-  static constexpr int LD = TILE + 4;  // LDS row stride (floats)
-  static constexpr int VPR = TILE / 4;
-  static constexpr int RPP = NTHREADS / VPR;
-  struct P { const float* w; ConvGeom g; int cols; int K; };
-  const float* base; int c4, kr0, K, Ko, C; long RSC; bool ok;
-  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
-    c4 = tid % VPR; kr0 = tid / VPR; K = p.K; Ko = p.g.Ko; C = p.g.C; RSC = (long)p.g.R * p.g.S * p.g.C;
-    ok = idx0 + c4 * 4 < p.cols; base = p.w + idx0 + c4 * 4;
-  }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int k = k0 + kr0 + j * RPP;
-      const int tap = k / Ko, ko = k - tap * Ko;
-      v[j] = (ok && k < K) ? *reinterpret_cast<const float4*>(base + (long)ko * RSC + (long)tap * C) : zero4();
-    }
-  }
-  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) store2_mc<LDT>(hi, lo, c4 * 4, kr0 + j * RPP, v[j]);
-  }
-  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-      *reinterpret_cast<float4*>(Sm + (kr0 + j * RPP) * LD + c4 * 4) = v[j];
-  }
-};
-
-// Stride-2 dgrad, one output-parity class (ph,pw) per launch: only the taps r = (ph+pad) mod 2 (+2) reach pixels
-// (2a+ph, 2b+pw), so the K loop runs over those taps only (no multiply-by-zero work: 9 taps -> 1+2+2+4 over the
-// four classes).  idx = (n,a,b) on the half-resolution grid; k = (ti,ko) with ti indexing the class's tap list.
-struct S2Taps { int nr, ns; int r[2], s[2]; int dr[2], ds[2]; };  // ho = a + dr[tr], wo = b + ds[ts]
-
-template <int TILE>
-struct ConvDgradS2KC {
-  static constexpr bool KC = true;
-  static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
-  static constexpr int LD = TILE + 1;  // LDS row stride (floats)
-  struct P { const float* dy; ConvGeom g; S2Taps t; int Hs, Ws; int rows; int K; };
-  long nbase[NV]; int pa[NV], pb[NV];
-  const float* dy; int k4, r0, K, Ho, Wo, Ko; S2Taps t;
-  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
-    k4 = tid & 7; r0 = tid >> 3; K = p.K; dy = p.dy; Ho = p.g.Ho; Wo = p.g.Wo; Ko = p.g.Ko; t = p.t;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int row = idx0 + r0 + j * 32;
-      if (row < p.rows) {
-        const int b = row % p.Ws; const int q = row / p.Ws; const int a = q % p.Hs; const int n = q / p.Hs;
-        pa[j] = a; pb[j] = b; nbase[j] = (long)n * Ho * Wo * Ko;
-      } else { pa[j] = -(1 << 28); pb[j] = 0; nbase[j] = 0; }
-    }
-  }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
-    const int k = k0 + k4 * 4;
-    const int ti = k / Ko, ko = k - ti * Ko;
-    const int tr = ti / t.ns, ts = ti - tr * t.ns;
-    const int dr = tr == 0 ? t.dr[0] : t.dr[1], ds = ts == 0 ? t.ds[0] : t.ds[1];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int ho = pa[j] + dr, wo = pb[j] + ds;
-      const bool ok = (k < K) && ((unsigned)ho < (unsigned)Ho) && ((unsigned)wo < (unsigned)Wo);
-      v[j] = ok ? *reinterpret_cast<const float4*>(dy + nbase[j] + ((long)ho * Wo + wo) * Ko + ko) : zero4();
-    }
-  }
-  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) store2_kc(hi, lo, r0 + j * 32, k4 * 4, v[j]);
-  }
-  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      float* d = Sm + (k4 * 4) * LD + r0 + j * 32;
-      d[0] = v[j].x; d[LD] = v[j].y; d[2 * LD] = v[j].z; d[3 * LD] = v[j].w;
-    }
-  }
-};
-
-template <int TILE>
-struct ConvFilterS2MC {
-  static constexpr bool KC = false;
-  static constexpr int LDT = TILE + 32;
-  static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
-  static constexpr int LD = TILE + 4;  // LDS row stride (floats)
-  static constexpr int VPR = TILE / 4;
-  static constexpr int RPP = NTHREADS / VPR;
-  struct P { const float* w; ConvGeom g; S2Taps t; int cols; int K; };
-  const float* base; int c4, kr0, K, Ko, C, S; long RSC; bool ok; S2Taps t;
-  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
-    c4 = tid % VPR; kr0 = tid / VPR; K = p.K; Ko = p.g.Ko; C = p.g.C; S = p.g.S; RSC = (long)p.g.R * p.g.S * p.g.C; t = p.t;
-    ok = idx0 + c4 * 4 < p.cols; base = p.w + idx0 + c4 * 4;
-  }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int k = k0 + kr0 + j * RPP;
-      const int ti = k / Ko, ko = k - ti * Ko;
-      const int tr = ti / t.ns, ts = ti - tr * t.ns;
-      const int tap = (tr == 0 ? t.r[0] : t.r[1]) * S + (ts == 0 ? t.s[0] : t.s[1]);
-      v[j] = (ok && k < K) ? *reinterpret_cast<const float4*>(base + (long)ko * RSC + (long)tap * C) : zero4();
-    }
-  }
-  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) store2_mc<LDT>(hi, lo, c4 * 4, kr0 + j * RPP, v[j]);
-  }
-  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-      *reinterpret_cast<float4*>(Sm + (kr0 + j * RPP) * LD + c4 * 4) = v[j];
-  }
-};
-
-// wgrad B operand: k = (n,ho,wo), idx = (r,s,c) -> x[n][ho*st-pad+r][wo*st-pad+s][c]   (c contiguous)
-// The pixel index k only ever advances by BK between consecutive load() calls, so (n,ho,wo) is carried in
-// registers and stepped with add/compare instead of being re-derived with integer divisions every K-tile.
-template <int TILE>
-struct ConvIm2colMC {
-  static constexpr bool KC = false;
-  static constexpr int LDT = TILE + 32;
-  static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
-  static constexpr int LD = TILE + 4;  // LDS row stride (floats)
-  static constexpr int VPR = TILE / 4;
-  static constexpr int RPP = NTHREADS / VPR;
-  struct P { const float* x; ConvGeom g; int cols; int K; };
-  const float* x; int c4, kr0, K, H, W, C, Ho, Wo, st, dh, dw; long coff; bool ok;
-  int pn[NV], pho[NV], pwo[NV], knext;
-  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
-    c4 = tid % VPR; kr0 = tid / VPR; K = p.K; x = p.x; H = p.g.H; W = p.g.W; C = p.g.C; Ho = p.g.Ho; Wo = p.g.Wo; st = p.g.stride;
-    const int col = idx0 + c4 * 4;
-    ok = col < p.cols;
-    const int tap = col / C, c = col - tap * C;
-    const int r = tap / p.g.S, s = tap - r * p.g.S;
-    dh = r - p.g.pad; dw = s - p.g.pad; coff = c;
-    knext = -1;
-  }
-  __device__ __forceinline__ void seek(int k0) {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int k = k0 + kr0 + j * RPP;
-      pwo[j] = k % Wo; const int t = k / Wo; pho[j] = t % Ho; pn[j] = t / Ho;
-    }
-    knext = k0;
-  }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
-    if (k0 != knext) seek(k0);
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int k = k0 + kr0 + j * RPP;
-      const int hi = pho[j] * st + dh, wi = pwo[j] * st + dw;
-      const bool in = ok && (k < K) && ((unsigned)hi < (unsigned)H) && ((unsigned)wi < (unsigned)W);
-      v[j] = in ? *reinterpret_cast<const float4*>(x + (((long)pn[j] * H + hi) * W + wi) * C + coff) : zero4();
-      // advance this row's pixel by BK for the next K-tile
-      int wo = pwo[j] + BK, ho = pho[j], n = pn[j];
-      while (wo >= Wo) { wo -= Wo; if (++ho == Ho) { ho = 0; ++n; } }
-      pwo[j] = wo; pho[j] = ho; pn[j] = n;
-    }
-    knext = k0 + BK;
-  }
-  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j) store2_mc<LDT>(hi, lo, c4 * 4, kr0 + j * RPP, v[j]);
-  }
-  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const {
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-      *reinterpret_cast<float4*>(Sm + (kr0 + j * RPP) * LD + c4 * 4) = v[j];
-  }
-};
+}  // namespace cxrk
+#include "gemm_loaders.h"
+namespace cxrk {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Kernel

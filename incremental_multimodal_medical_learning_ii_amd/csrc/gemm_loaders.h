@@ -1,0 +1,472 @@
+// Operand loaders of the MFMA mainloops (included by gemm_core.h).
+//
+// A loader turns an (idx, k) tile coordinate into global loads of 16 B per lane and stages the values into LDS.
+// TILE = extent of the idx dimension in the block tile.  Every loader exposes
+//   P (host-filled parameters), init(P, idx0, tid), load(k0, v[NV]), store(S, v[NV]), store2(hi, lo, v[NV]).
+// load() must be called with k0 advancing by BK from one call to the next (any start): the convolution loaders carry
+// the filter tap / pixel position of k0 as wave-uniform state instead of re-deriving it with integer divisions.
+//
+// Addressing.  The mainloop is bound by vector-ALU issue, not by the matrix pipe (rocprofv3 SQ_INSTS_VALU / SQ_INSTS_MFMA
+// was 10 for the dense and 16-27 for the convolution loaders when every load carried its own 64-bit address, bounds
+// compare and branch), so the loaders spend as few vector instructions per load as possible:
+//  * every load is a buffer_load_dwordx4 through a per-K-tile descriptor whose base holds everything that is uniform over
+//    the block (tile origin, k0, the filter tap): scalar ALU only;
+//  * what depends on the lane is ONE 32-bit byte offset per load, computed once in init();
+//  * a lane that must read zero (row outside the tensor, padding halo, K tail) gets bit 31 set in its offset: the
+//    descriptor declares 2^31 bytes, so the hardware range check returns 0 and no branch or select guards the load.
+//    Convolution halos are a per-row bit mask over the (<= 32) filter taps, tested with one v_bfe_u32 per load.
+// A block's loads stay within 2 GiB of its tile origin (host-side checks in launch_gemm's callers).
+#pragma once
+
+namespace cxrk {
+
+constexpr unsigned VOFF_OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)0x80000000, 0x00020000);
+}
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  // bit_cast, not a conversion: the builtin returns a 128-bit scalar-like value, and converting THAT to a vector splats
+  // its low dword (the compiler then narrows the load to buffer_load_dword)
+  const auto q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+  static_assert(sizeof(q) == 16, "raw_buffer_load_b128 must return 16 bytes");
+  const f32x4 f = __builtin_bit_cast(f32x4, q);
+  return make_float4(f[0], f[1], f[2], f[3]);
+}
+// offset | (bit t of inv ? OOB : 0): two vector instructions (v_bfe_u32, v_lshl_or_b32)
+__device__ __forceinline__ unsigned masked_off(unsigned off, unsigned inv, int t) {
+  return (__builtin_amdgcn_ubfe(inv, (unsigned)t, 1u) << 31) | off;
+}
+
+// ---- LDS staging shared by the loaders -------------------------------------------------------------------------------
+// K-contiguous operand (k4 = tid & 7 -> 4 consecutive k, r0 = tid >> 3 -> row, +32 rows per j)
+template <int NV, int LD>
+__device__ __forceinline__ void stage_kc(float* S, int r0, int k4, const float4 (&v)[NV]) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    float* d = S + (k4 * 4) * LD + r0 + j * 32;
+    d[0] = v[j].x; d[LD] = v[j].y; d[2 * LD] = v[j].z; d[3 * LD] = v[j].w;
+  }
+}
+template <int NV>
+__device__ __forceinline__ void stage2_kc(unsigned short* hi, unsigned short* lo, int r0, int k4, const float4 (&v)[NV]) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j) store2_kc(hi, lo, r0 + j * 32, k4 * 4, v[j]);
+}
+// idx-contiguous operand (c4 = tid % VPR -> 4 consecutive idx, kr0 = tid / VPR -> k row, +RPP rows per j)
+template <int NV, int LD, int RPP>
+__device__ __forceinline__ void stage_mc(float* S, int kr0, int c4, const float4 (&v)[NV]) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j) *reinterpret_cast<float4*>(S + (kr0 + j * RPP) * LD + c4 * 4) = v[j];
+}
+template <int NV, int LDT, int RPP>
+__device__ __forceinline__ void stage2_mc(unsigned short* hi, unsigned short* lo, int kr0, int c4, const float4 (&v)[NV]) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j) store2_mc<LDT>(hi, lo, c4 * 4, kr0 + j * RPP, v[j]);
+}
+
+// X(idx, k) = ptr[idx*ld + k]   (k contiguous)
+template <int TILE>
+struct DenseKC {
+  static constexpr bool KC = true;
+  static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
+  static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 1;  // LDS row stride (floats)
+  struct P { const float* ptr; long ld; int rows; int K; };
+  const float* bp; unsigned voff[NV]; int k4, r0, K;
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    k4 = tid & 7; r0 = tid >> 3; K = p.K;
+    bp = p.ptr + (long)idx0 * p.ld;
+    const int ld = (int)p.ld;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      voff[j] = idx0 + r0 + j * 32 < p.rows ? (unsigned)(((r0 + j * 32) * ld + k4 * 4) * 4) : VOFF_OOB;
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + k0);
+    if (k0 + BK <= K) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[j] = bload4(rs, voff[j]);
+    } else {  // K tail (the last K-tile only)
+      const unsigned t = k0 + k4 * 4 < K ? 0u : VOFF_OOB;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[j] = bload4(rs, voff[j] | t);
+    }
+  }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_kc<NV>(hi, lo, r0, k4, v); }
+  __device__ __forceinline__ void store(float* S, const float4 (&v)[NV]) const { stage_kc<NV, LD>(S, r0, k4, v); }
+};
+
+// X(idx, k) = ptr[k*ld + idx]   (idx contiguous)
+template <int TILE>
+struct DenseMC {
+  static constexpr bool KC = false;
+  static constexpr int LDT = TILE + 32;
+  static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
+  static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 4;  // LDS row stride (floats)
+  static constexpr int VPR = TILE / 4;          // float4 per k-row
+  static constexpr int RPP = NTHREADS / VPR;    // k-rows per pass
+  struct P { const float* ptr; long ld; int cols; int K; };
+  const float* bp; long ld_; unsigned voff[NV];
+  int c4, kr0, K;
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    c4 = tid % VPR; kr0 = tid / VPR; K = p.K; ld_ = p.ld;
+    bp = p.ptr + idx0;
+    const bool ok = idx0 + c4 * 4 < p.cols;
+    const int ld = (int)p.ld;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) voff[j] = ok ? (unsigned)(((kr0 + j * RPP) * ld + c4 * 4) * 4) : VOFF_OOB;
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + (long)k0 * ld_);
+    if (k0 + BK <= K) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[j] = bload4(rs, voff[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[j] = bload4(rs, k0 + kr0 + j * RPP < K ? voff[j] : VOFF_OOB);
+    }
+  }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_mc<NV, LDT, RPP>(hi, lo, kr0, c4, v); }
+  __device__ __forceinline__ void store(float* S, const float4 (&v)[NV]) const { stage_mc<NV, LD, RPP>(S, kr0, c4, v); }
+};
+
+// NHWC geometry shared by the convolution gathers.
+struct ConvGeom {
+  int N, H, W, C;        // input  x[N][H][W][C]
+  int Ho, Wo, Ko;        // output y[N][Ho][Wo][Ko]
+  int R, S, stride, pad; // filter w[Ko][R][S][C]
+};
+
+// fprop A operand: idx = (n,ho,wo), k = (r,s,c) -> x[n][ho*st-pad+r][wo*st-pad+s][c]   (c contiguous)
+// TAPWISE: C % BK == 0, so a K-tile lies inside ONE filter tap (r,s): the tap is wave-uniform state, the halo a bit mask
+// over the R*S <= 32 taps.  Otherwise (the stem: C = 4, 49 taps) every lane derives its own tap.
+template <int TILE, bool TAPWISE = true>
+struct ConvIm2colKC {
+  static constexpr bool KC = true;
+  static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
+  static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 1;  // LDS row stride (floats)
+  struct P { const float* x; ConvGeom g; int rows; int K; };
+  const float* bp;
+  unsigned off[NV];                 // byte offset of (row, tap 0, c = 4*k4) from bp   [TAPWISE: >= 0 by construction]
+  unsigned inv[NV];                 // TAPWISE: bit (r*S+s) set = that tap falls outside the image for this row
+  int hi0[NV], wi0[NV];             // !TAPWISE
+  int k4, r0, K, H, W, C, S;
+  int tr, ts, tc, knext;            // TAPWISE: tap (tr,ts) and channel offset tc of K-tile `knext` (wave-uniform)
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    k4 = tid & 7; r0 = tid >> 3; K = p.K; H = p.g.H; W = p.g.W; C = p.g.C; S = p.g.S;
+    const int HoWo = p.g.Ho * p.g.Wo;
+    const int n_first = idx0 / HoWo;
+    // bias so that off >= 0 for every row of the tile: the halo can reach `pad` rows / columns before the image
+    const int bias = TAPWISE ? (p.g.pad * W + p.g.pad) * C : 0;
+    bp = p.x + (long)n_first * H * W * C - bias;
+    knext = -1; tr = ts = tc = 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int row = idx0 + r0 + j * 32;
+      if (row < p.rows) {
+        const int wo = row % p.g.Wo; const int t = row / p.g.Wo; const int ho = t % p.g.Ho; const int n = t / p.g.Ho;
+        const int h0 = ho * p.g.stride - p.g.pad, w0 = wo * p.g.stride - p.g.pad;
+        off[j] = (unsigned)(((((n - n_first) * H + h0) * W + w0) * C + bias + (TAPWISE ? k4 * 4 : 0)) * 4);
+        if (TAPWISE) {
+          unsigned m = 0;
+          for (int r = 0; r < p.g.R; ++r)
+            for (int s = 0; s < S; ++s)
+              if ((unsigned)(h0 + r) >= (unsigned)H || (unsigned)(w0 + s) >= (unsigned)W) m |= 1u << (r * S + s);
+          inv[j] = m;
+        } else { hi0[j] = h0; wi0[j] = w0; }
+      } else { off[j] = 0; inv[j] = 0xffffffffu; hi0[j] = -(1 << 28); wi0[j] = 0; }
+    }
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
+    if constexpr (TAPWISE) {
+      if (k0 != knext) { const int tap = k0 / C; tc = k0 - tap * C; tr = tap / S; ts = tap - tr * S; }
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + ((long)(tr * W + ts) * C + tc));
+      const int t = tr * S + ts;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[j] = bload4(rs, masked_off(off[j], inv[j], t));
+      tc += BK;
+      if (tc >= C) { tc = 0; if (++ts == S) { ts = 0; ++tr; } }
+      knext = k0 + BK;
+    } else {
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp);
+      const int k = k0 + k4 * 4;
+      const int tap = k / C, c = k - tap * C;
+      const int r = tap / S, s = tap - r * S;
+      const unsigned toff = (unsigned)(((r * W + s) * C + c) * 4);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const bool ok = (k < K) && ((unsigned)(hi0[j] + r) < (unsigned)H) && ((unsigned)(wi0[j] + s) < (unsigned)W);
+        v[j] = bload4(rs, ok ? off[j] + toff : VOFF_OOB);
+      }
+    }
+  }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_kc<NV>(hi, lo, r0, k4, v); }
+  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const { stage_kc<NV, LD>(Sm, r0, k4, v); }
+};
+
+// dgrad A operand (stride 1): idx = (n,hi,wi), k = (r,s,ko) -> dy[n][hi+pad-r][wi+pad-s][ko].  Ko % BK == 0: a K-tile
+// lies inside one tap.  Stride-2 layers go through ConvDgradS2KC.
+template <int TILE>
+struct ConvDgradKC {
+  static constexpr bool KC = true;
+  static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
+  static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 1;  // LDS row stride (floats)
+  struct P { const float* dy; ConvGeom g; int rows; int K; };
+  const float* bp; unsigned off[NV], inv[NV];
+  int k4, r0, Wo, Ko, R, S;
+  int tr, ts, tk, knext;  // tap (tr,ts), channel offset tk of K-tile `knext`
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    k4 = tid & 7; r0 = tid >> 3; Wo = p.g.Wo; Ko = p.g.Ko; R = p.g.R; S = p.g.S;
+    const int Ho = p.g.Ho, H = p.g.H, W = p.g.W, pad = p.g.pad;
+    const int n_first = idx0 / (H * W);
+    // address of tap (r,s) = bp + [((R-1-r)*Wo + (S-1-s))*Ko + ko0]  (uniform, >= 0)  +  off[row]  (>= 0)
+    bp = p.dy + ((long)n_first * Ho * Wo - ((R - 1) * Wo + (S - 1))) * Ko;
+    knext = -1; tr = ts = tk = 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int row = idx0 + r0 + j * 32;
+      if (row < p.rows) {
+        const int wi = row % W; const int t = row / W; const int hi = t % H; const int n = t / H;
+        off[j] = (unsigned)(((((n - n_first) * Ho + hi + pad) * Wo + wi + pad) * Ko + k4 * 4) * 4);
+        unsigned m = 0;
+        for (int r = 0; r < R; ++r)
+          for (int s = 0; s < S; ++s)
+            if ((unsigned)(hi + pad - r) >= (unsigned)Ho || (unsigned)(wi + pad - s) >= (unsigned)Wo) m |= 1u << (r * S + s);
+        inv[j] = m;
+      } else { off[j] = 0; inv[j] = 0xffffffffu; }
+    }
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
+    if (k0 != knext) { const int tap = k0 / Ko; tk = k0 - tap * Ko; tr = tap / S; ts = tap - tr * S; }
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + ((long)((R - 1 - tr) * Wo + (S - 1 - ts)) * Ko + tk));
+    const int t = tr * S + ts;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = bload4(rs, masked_off(off[j], inv[j], t));
+    tk += BK;
+    if (tk >= Ko) { tk = 0; if (++ts == S) { ts = 0; ++tr; } }
+    knext = k0 + BK;
+  }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_kc<NV>(hi, lo, r0, k4, v); }
+  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const { stage_kc<NV, LD>(Sm, r0, k4, v); }
+};
+
+// dgrad B operand: k = (r,s,ko), idx = c -> w[ko][r][s][c]   (c contiguous)
+template <int TILE>
+struct ConvFilterMC {
+  static constexpr bool KC = false;
+  static constexpr int LDT = TILE + 32;
+  static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
+  static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 4;  // LDS row stride (floats)
+  static constexpr int VPR = TILE / 4;
+  static constexpr int RPP = NTHREADS / VPR;
+  struct P { const float* w; ConvGeom g; int cols; int K; };
+  const float* bp; unsigned voff[NV]; int c4, kr0, Ko, C; long RSC;
+  int tap, tk, knext;
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    c4 = tid % VPR; kr0 = tid / VPR; Ko = p.g.Ko; C = p.g.C; RSC = (long)p.g.R * p.g.S * p.g.C;
+    bp = p.w + idx0;
+    const bool ok = idx0 + c4 * 4 < p.cols;
+    knext = -1; tap = tk = 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) voff[j] = ok ? (unsigned)(((kr0 + j * RPP) * (int)RSC + c4 * 4) * 4) : VOFF_OOB;
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
+    if (k0 != knext) { tap = k0 / Ko; tk = k0 - tap * Ko; }
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + ((long)tk * RSC + (long)tap * C));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = bload4(rs, voff[j]);
+    tk += BK;
+    if (tk >= Ko) { tk = 0; ++tap; }
+    knext = k0 + BK;
+  }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_mc<NV, LDT, RPP>(hi, lo, kr0, c4, v); }
+  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const { stage_mc<NV, LD, RPP>(Sm, kr0, c4, v); }
+};
+
+// Stride-2 dgrad, one output-parity class (ph,pw) per launch: only the taps r = (ph+pad) mod 2 (+2) reach pixels
+// (2a+ph, 2b+pw), so the K loop runs over those taps only (no multiply-by-zero work: 9 taps -> 1+2+2+4 over the
+// four classes).  idx = (n,a,b) on the half-resolution grid; k = (ti,ko) with ti indexing the class's tap list.
+struct S2Taps { int nr, ns; int r[2], s[2]; int dr[2], ds[2]; };  // ho = a + dr[tr], wo = b + ds[ts]   (dr, ds >= 0)
+
+template <int TILE>
+struct ConvDgradS2KC {
+  static constexpr bool KC = true;
+  static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
+  static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 1;  // LDS row stride (floats)
+  struct P { const float* dy; ConvGeom g; S2Taps t; int Hs, Ws; int rows; int K; };
+  const float* bp; unsigned off[NV], inv[NV];
+  int k4, r0, Wo, Ko; S2Taps t;
+  int ti, tk, knext;
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    k4 = tid & 7; r0 = tid >> 3; Wo = p.g.Wo; Ko = p.g.Ko; t = p.t;
+    const int Ho = p.g.Ho;
+    const int n_first = idx0 / (p.Hs * p.Ws);
+    bp = p.dy + (long)n_first * Ho * Wo * Ko;
+    knext = -1; ti = tk = 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int row = idx0 + r0 + j * 32;
+      if (row < p.rows) {
+        const int b = row % p.Ws; const int q = row / p.Ws; const int a = q % p.Hs; const int n = q / p.Hs;
+        off[j] = (unsigned)(((((n - n_first) * Ho + a) * Wo + b) * Ko + k4 * 4) * 4);
+        unsigned m = 0;
+        for (int ir = 0; ir < t.nr; ++ir)
+          for (int is = 0; is < t.ns; ++is)
+            if (a + t.dr[ir] >= Ho || b + t.ds[is] >= Wo) m |= 1u << (ir * t.ns + is);
+        inv[j] = m;
+      } else { off[j] = 0; inv[j] = 0xffffffffu; }
+    }
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
+    if (k0 != knext) { ti = k0 / Ko; tk = k0 - ti * Ko; }
+    const int ir = ti / t.ns, is = ti - ir * t.ns;
+    const int dr = ir == 0 ? t.dr[0] : t.dr[1], ds = is == 0 ? t.ds[0] : t.ds[1];
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + ((long)(dr * Wo + ds) * Ko + tk));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = bload4(rs, masked_off(off[j], inv[j], ti));
+    tk += BK;
+    if (tk >= Ko) { tk = 0; ++ti; }
+    knext = k0 + BK;
+  }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_kc<NV>(hi, lo, r0, k4, v); }
+  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const { stage_kc<NV, LD>(Sm, r0, k4, v); }
+};
+
+template <int TILE>
+struct ConvFilterS2MC {
+  static constexpr bool KC = false;
+  static constexpr int LDT = TILE + 32;
+  static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
+  static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 4;  // LDS row stride (floats)
+  static constexpr int VPR = TILE / 4;
+  static constexpr int RPP = NTHREADS / VPR;
+  struct P { const float* w; ConvGeom g; S2Taps t; int cols; int K; };
+  const float* bp; unsigned voff[NV]; int c4, kr0, Ko, C, S; long RSC; S2Taps t;
+  int ti, tk, knext;
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    c4 = tid % VPR; kr0 = tid / VPR; Ko = p.g.Ko; C = p.g.C; S = p.g.S; RSC = (long)p.g.R * p.g.S * p.g.C; t = p.t;
+    bp = p.w + idx0;
+    const bool ok = idx0 + c4 * 4 < p.cols;
+    knext = -1; ti = tk = 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) voff[j] = ok ? (unsigned)(((kr0 + j * RPP) * (int)RSC + c4 * 4) * 4) : VOFF_OOB;
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
+    if (k0 != knext) { ti = k0 / Ko; tk = k0 - ti * Ko; }
+    const int ir = ti / t.ns, is = ti - ir * t.ns;
+    const int tap = (ir == 0 ? t.r[0] : t.r[1]) * S + (is == 0 ? t.s[0] : t.s[1]);
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + ((long)tk * RSC + (long)tap * C));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = bload4(rs, voff[j]);
+    tk += BK;
+    if (tk >= Ko) { tk = 0; ++ti; }
+    knext = k0 + BK;
+  }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_mc<NV, LDT, RPP>(hi, lo, kr0, c4, v); }
+  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const { stage_mc<NV, LD, RPP>(Sm, kr0, c4, v); }
+};
+
+// wgrad B operand: k = (n,ho,wo), idx = (r,s,c) -> x[n][ho*st-pad+r][wo*st-pad+s][c]   (c contiguous)
+// A lane keeps its (r,s,c) for the whole K loop; its NV pixels advance by BK per K-tile.
+//  * "same" stride-1 convolutions (Ho == H, Wo == W): the pixel index IS k, so the address is linear in k: uniform base
+//    k0*C + a fixed lane offset.  1x1: nothing else to do.  3x3: the halo test needs (ho,wo) of each pixel, carried per
+//    lane and stepped by (BK / Wo, BK % Wo) with a carry (no division).
+//  * otherwise (stride 2): image / row / column of each pixel are carried the same way and the address is rebuilt from
+//    them, relative to the image of pixel k0 (wave-uniform, stepped alongside).
+template <int TILE>
+struct ConvIm2colMC {
+  static constexpr bool KC = false;
+  static constexpr int LDT = TILE + 32;
+  static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
+  static constexpr int NV = TILE / 32;
+  static constexpr int LD = TILE + 4;  // LDS row stride (floats)
+  static constexpr int VPR = TILE / 4;
+  static constexpr int RPP = NTHREADS / VPR;
+  struct P { const float* x; ConvGeom g; int cols; int K; };
+  const float* x; int c4, kr0, K, H, W, C, Ho, Wo, st, dh, dw, cc, bias; bool ok;
+  bool linear, halo;
+  unsigned voff[NV];                       // linear mode: fixed lane offsets from x - bias + k0*C
+  int pn[NV], pho[NV], pwo[NV];            // pixel (image, row, column) of this lane's j-th k-row in K-tile `knext`
+  int stepq, stepr;                        // BK = stepq * Wo + stepr
+  int un, urem, knext;                     // wave-uniform: image of pixel `knext` and its index inside that image
+  __device__ __forceinline__ void init(const P& p, int idx0, int tid) {
+    c4 = tid % VPR; kr0 = tid / VPR; K = p.K; x = p.x; H = p.g.H; W = p.g.W; C = p.g.C; Ho = p.g.Ho; Wo = p.g.Wo; st = p.g.stride;
+    const int col = idx0 + c4 * 4;
+    ok = col < p.cols;
+    const int tap = col / C; cc = col - tap * C;
+    const int r = tap / p.g.S, s = tap - r * p.g.S;
+    dh = r - p.g.pad; dw = s - p.g.pad;
+    linear = (st == 1 && Ho == H && Wo == W);
+    halo = (p.g.R * p.g.S > 1) || p.g.pad != 0;
+    stepq = BK / Wo; stepr = BK - stepq * Wo;
+    knext = -1; un = urem = 0;
+    bias = (p.g.pad * W + p.g.pad) * C;   // keeps the linear-mode lane offset >= 0
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      voff[j] = ok ? (unsigned)(((kr0 + j * RPP + dh * W + dw) * C + cc + bias) * 4) : VOFF_OOB;
+      pn[j] = pho[j] = pwo[j] = 0;
+    }
+  }
+  __device__ __forceinline__ void seek(int k0) {
+    const int HoWo = Ho * Wo;
+    un = k0 / HoWo; urem = k0 - un * HoWo;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int k = k0 + kr0 + j * RPP;
+      pwo[j] = k % Wo; const int t = k / Wo; pho[j] = t % Ho; pn[j] = t / Ho;
+    }
+  }
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
+    if (k0 != knext) seek(k0);
+    const bool tail = k0 + BK > K;
+    if (linear) {
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(x + ((long)k0 * C - bias));
+      if (!halo && !tail) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = bload4(rs, voff[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          bool valid = ((unsigned)(pho[j] + dh) < (unsigned)H) && ((unsigned)(pwo[j] + dw) < (unsigned)W);
+          if (tail) valid = valid && (k0 + kr0 + j * RPP < K);
+          v[j] = bload4(rs, valid ? voff[j] : VOFF_OOB);
+        }
+      }
+    } else {
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(x + (long)un * H * W * C);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int hi = pho[j] * st + dh, wi = pwo[j] * st + dw;
+        bool valid = ok && ((unsigned)hi < (unsigned)H) && ((unsigned)wi < (unsigned)W);
+        if (tail) valid = valid && (k0 + kr0 + j * RPP < K);
+        const unsigned o = (unsigned)(((((pn[j] - un) * H + hi) * W + wi) * C + cc) * 4);
+        v[j] = bload4(rs, valid ? o : VOFF_OOB);
+      }
+    }
+    if (halo || !linear) {  // step every pixel by BK
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        int wo = pwo[j] + stepr, ho = pho[j] + stepq;
+        if (wo >= Wo) { wo -= Wo; ++ho; }
+        int n = pn[j];
+        while (ho >= Ho) { ho -= Ho; ++n; }   // one iteration at most unless the image is narrower than BK / Ho
+        pwo[j] = wo; pho[j] = ho; pn[j] = n;
+      }
+      urem += BK;
+      const int HoWo = Ho * Wo;
+      while (urem >= HoWo) { urem -= HoWo; ++un; }
+    }
+    knext = k0 + BK;
+  }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_mc<NV, LDT, RPP>(hi, lo, kr0, c4, v); }
+  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const { stage_mc<NV, LD, RPP>(Sm, kr0, c4, v); }
+};
+
+}  // namespace cxrk
