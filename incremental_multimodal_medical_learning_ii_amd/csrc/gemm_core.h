@@ -16,6 +16,7 @@
 //   tile list, so the A panel is re-read from that XCD's L2 rather than from HBM.
 #pragma once
 #include "cxrk_common.h"
+#include <cstdlib>
 
 #ifndef CXRK_ABL
 #define CXRK_ABL 0  // ablation switch for scripts/tune_gemm.hip only; the library is always built with 0
@@ -230,6 +231,28 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const EpiPara
   }
 }
 
+// XCD-aware tile mapping (speed only, never correctness).  Workgroups are dealt round-robin over the 8 XCDs, so blocks b
+// and b+8 share an L2.  Bijective remap (cdna_hip_programming.md T1): XCD x owns a contiguous chunk of the tile list, so
+// every XCD gets work even when there are fewer than 8 M panels.  Inside the list the tiles are ordered in column chunks
+// of CXRK_GN N-tiles, M-panel-major inside a chunk: the blocks an XCD runs at the same time then share a few B panels
+// (they stay in its 4 MiB L2) while the A panels stream through, each re-read CXRK_GN times back to back.
+#ifndef CXRK_GN
+#define CXRK_GN 8   // 0 = one chunk = plain M-panel-major order; 8: +3..7 % on the BERT GEMMs (N = 2304 / 3072) over 0
+#endif
+__device__ __forceinline__ void tile_coords(int nMt, int nNt, int& mt, int& nt) {
+  const int nwg = nMt * nNt;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, idx = b >> 3;
+  const int qq = nwg >> 3, rr = nwg & 7;
+  const int wgid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+  if (CXRK_GN <= 0 || nNt <= CXRK_GN) { mt = wgid / nNt; nt = wgid - mt * nNt; return; }
+  const int per = nMt * CXRK_GN;            // tiles of a full chunk
+  const int c = wgid / per, rem = wgid - c * per;
+  const int width = min(CXRK_GN, nNt - c * CXRK_GN);
+  mt = rem / width;                         // the last (narrower) chunk still holds nMt * width tiles
+  nt = c * CXRK_GN + (rem - mt * width);
+}
+
 #ifndef CXRK_OCC
 #define CXRK_OCC ((WM == 2 && WN == 2) ? 3 : 2)  // the 256x64 / 64x256 tiles stage more registers: at 3 waves/SIMD they spill
 #endif
@@ -253,17 +276,8 @@ __global__ __launch_bounds__(NTHREADS, CXRK_OCC) void gemm_f32_kernel(typename L
   float* const As0 = smem;
   float* const Bs0 = smem + NBUF * ASZ;
 
-  // XCD-aware tile mapping (speed only, never correctness).  Workgroups are dealt round-robin over the 8 XCDs, so
-  // blocks b and b+8 share an L2.  Bijective remap (cdna_hip_programming.md T1): XCD x owns a contiguous chunk of
-  // the tile list; tiles are ordered M-panel-major, so an XCD walks all N tiles of a panel back to back (A panel
-  // re-read from its own L2) and every XCD gets work even when there are fewer than 8 M panels.
-  const int nwg = nMt * nNt;
-  const int b = blockIdx.x;
-  const int xcd = b & 7, idx = b >> 3;
-  const int qq = nwg >> 3, rr = nwg & 7;
-  const int wgid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
-  const int mt = wgid / nNt;
-  const int nt = wgid - mt * nNt;
+  int mt, nt;
+  tile_coords(nMt, nNt, mt, nt);
   const int m0 = mt * BM, n0 = nt * BN;
   const int z = blockIdx.y;
   const int kbeg = z * kchunk;
@@ -353,13 +367,8 @@ __global__ __launch_bounds__(NTHREADS, (WM == 2 && WN == 2) ? 3 : 2) void gemm_x
   unsigned short* const Bhi = Alo + PLANE_A;
   unsigned short* const Blo = Bhi + PLANE_B;
 
-  const int nwg = nMt * nNt;
-  const int b = blockIdx.x;
-  const int xcd = b & 7, idx = b >> 3;
-  const int qq = nwg >> 3, rr = nwg & 7;
-  const int wgid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
-  const int mt = wgid / nNt;
-  const int nt = wgid - mt * nNt;
+  int mt, nt;
+  tile_coords(nMt, nNt, mt, nt);
   const int m0 = mt * BM, n0 = nt * BN;
   const int z = blockIdx.y;
   const int kbeg = z * kchunk;
@@ -418,16 +427,143 @@ __global__ __launch_bounds__(NTHREADS, (WM == 2 && WN == 2) ? 3 : 2) void gemm_x
         }
     }
     __syncthreads();  // everyone is done reading before the single buffer is overwritten
-    if (k0 + BK < kend) { la.store2(Ahi, Alo, ra); lb.store2(Bhi, Blo, rb); }
+    if (k0 + BK < kend && !(CXRK_ABL & 2)) { la.store2(Ahi, Alo, ra); lb.store2(Bhi, Blo, rb); }
     __syncthreads();
-    if (k0 + 2 * BK < kend) { la.load(k0 + 2 * BK, ra); lb.load(k0 + 2 * BK, rb); }
+    if (k0 + 2 * BK < kend) { la.load(k0 + 2 * BK, ra, !(CXRK_ABL & 1)); lb.load(k0 + 2 * BK, rb, !(CXRK_ABL & 1)); }
   }
   __syncthreads();
+  if ((CXRK_ABL & 4) && acc[0][0][0] != 12345.678f) return;
+  gemm_epilogue<WM, WN>(acc, ep, reinterpret_cast<float*>(smem16), M, N, m0, n0, mt, z, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Software-pipelined split-bf16 mainloop (128x128 tile).  The single-buffer kernel above runs its phases one after the
+// other -- MFMA block, barrier, convert + LDS store, barrier, global loads -- and the co-resident blocks of a CU fall into
+// lockstep, so the matrix pipe idles through every staging phase (SQ_VALU_MFMA_BUSY_CYCLES 30 %, SQ_WAIT_ANY 38 %).
+// Here a K-tile is ONE phase: two LDS buffers, tile t+1 is converted and stored into the other buffer between the MFMAs
+// of tile t, the loads of tile t+2 are issued behind them, and a single barrier closes the tile.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef CXRK_PIPE_SCHED
+#define CXRK_PIPE_SCHED 1
+#endif
+template <class LA, class LB>
+__device__ __forceinline__ void x3_mfma_block(const unsigned short* Ahi, const unsigned short* Alo, const unsigned short* Bhi,
+                                              const unsigned short* Blo, int wm, int wn, int kc, int lane, f32x16 (&acc)[2][2]) {
+  bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if constexpr (LA::KC) {
+      ah[i] = frag_kc(Ahi, wm * 64 + i * 32, kc, lane); al[i] = frag_kc(Alo, wm * 64 + i * 32, kc, lane);
+    } else {
+      ah[i] = frag_mc<LA::LDT>(Ahi, wm * 64 + i * 32, kc, lane); al[i] = frag_mc<LA::LDT>(Alo, wm * 64 + i * 32, kc, lane);
+    }
+    if constexpr (LB::KC) {
+      bh[i] = frag_kc(Bhi, wn * 64 + i * 32, kc, lane); bl[i] = frag_kc(Blo, wn * 64 + i * 32, kc, lane);
+    } else {
+      bh[i] = frag_mc<LB::LDT>(Bhi, wn * 64 + i * 32, kc, lane); bl[i] = frag_mc<LB::LDT>(Blo, wn * 64 + i * 32, kc, lane);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+// One K-tile of the pipelined loop.  (rc_a, rc_b) hold tile t+1 (loaded a whole tile ago), (rn_a, rn_b) receive tile t+2;
+// `cur` / `nxt` are the LDS buffers of tile t / t+1.  Stores and loads are unconditional -- past the end of the K range the
+// loads go through a zero-byte descriptor and the stores write zeros nobody reads -- so the body is one basic block and
+// the scheduler can lay the conversion and the LDS writes between the MFMAs (sched_group_barrier pattern below).
+template <class LA, class LB>
+__device__ __forceinline__ void x3p_tile(LA& la, LB& lb, float4 (&rc_a)[LA::NV], float4 (&rc_b)[LB::NV], float4 (&rn_a)[LA::NV],
+                                         float4 (&rn_b)[LB::NV], const unsigned short* cur, unsigned short* nxt, int k0, int kend,
+                                         int wm, int wn, int lane, f32x16 (&acc)[2][2]) {
+  constexpr int PLANE_A = LA::PLANE, PLANE_B = LB::PLANE;
+  const bool has2 = (k0 + 2 * BK < kend) && !(CXRK_ABL & 1);   // CXRK_ABL: tuning-harness ablations, 0 in the library
+  la.load(k0 + 2 * BK, rn_a, has2); lb.load(k0 + 2 * BK, rn_b, has2);
+  if (!(CXRK_ABL & 2)) la.store2(nxt, nxt + PLANE_A, rc_a);
+  x3_mfma_block<LA, LB>(cur, cur + PLANE_A, cur + 2 * PLANE_A, cur + 2 * PLANE_A + PLANE_B, wm, wn, 0, lane, acc);
+#if CXRK_PIPE_SCHED
+  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // fragment reads of the first half
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+  }
+#endif
+  if (!(CXRK_ABL & 2)) lb.store2(nxt + 2 * PLANE_A, nxt + 2 * PLANE_A + PLANE_B, rc_b);
+  x3_mfma_block<LA, LB>(cur, cur + PLANE_A, cur + 2 * PLANE_A, cur + 2 * PLANE_A + PLANE_B, wm, wn, 1, lane, acc);
+#if CXRK_PIPE_SCHED
+  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+  }
+#endif
+  __syncthreads();
+}
+
+template <class LA, class LB, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_x3p_kernel(typename LA::P pa, typename LB::P pb, EpiParams ep,
+                                                               int M, int N, int K, int nMt, int nNt, int kchunk) {
+  constexpr int BM = WM * 64, BN = WN * 64;
+  constexpr int PLANE_A = LA::PLANE, PLANE_B = LB::PLANE;  // halfwords
+  constexpr int BUF = 2 * (PLANE_A + PLANE_B);            // halfwords of one buffer (hi + lo planes of both operands)
+  static_assert(BUF * 2 >= 4 * 32 * 64 * 4, "operand LDS too small to stage the epilogue");
+  __shared__ __attribute__((aligned(16))) unsigned short smem16[2 * BUF];
+
+  int mt, nt;
+  tile_coords(nMt, nNt, mt, nt);
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int z = blockIdx.y;
+  const int kbeg = z * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  LA la; LB lb;
+  la.init(pa, m0, tid);
+  lb.init(pb, n0, tid);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // two register sets: set 0 = tiles 0, 2, 4, ..., set 1 = tiles 1, 3, 5, ...
+  float4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];
+  la.load(kbeg, ra0, kbeg < kend); lb.load(kbeg, rb0, kbeg < kend);
+  la.load(kbeg + BK, ra1, kbeg + BK < kend); lb.load(kbeg + BK, rb1, kbeg + BK < kend);
+  la.store2(smem16, smem16 + PLANE_A, ra0); lb.store2(smem16 + 2 * PLANE_A, smem16 + 2 * PLANE_A + PLANE_B, rb0);
+  __syncthreads();
+
+  for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+    x3p_tile<LA, LB>(la, lb, ra1, rb1, ra0, rb0, smem16, smem16 + BUF, k0, kend, wm, wn, lane, acc);
+    if (k0 + BK >= kend) break;
+    x3p_tile<LA, LB>(la, lb, ra0, rb0, ra1, rb1, smem16 + BUF, smem16, k0 + BK, kend, wm, wn, lane, acc);
+  }
+  if ((CXRK_ABL & 4) && acc[0][0][0] != 12345.678f) return;
   gemm_epilogue<WM, WN>(acc, ep, reinterpret_cast<float*>(smem16), M, N, m0, n0, mt, z, wave, lane);
 }
 
 // 0 = exact fp32 MFMA (default), 1 = split-bf16.  Process-wide, set through cxrk_set_precision().
 inline int& gemm_precision_mode() { static int mode = 0; return mode; }
+
+// Tuning switch (environment CXRK_PIPE, read once; default on): the software-pipelined split-bf16 mainloop for 128x128 tiles.
+inline bool pipelined_enabled() { static const bool on = [] { const char* e = getenv("CXRK_PIPE"); return e && e[0] == '1'; }(); return on; }
 
 // Host launcher.  splitk > 1 writes plain partial slabs (caller reduces them).
 template <class LA, class LB, int WM, int WN>
@@ -447,9 +583,16 @@ static int launch_gemm(const typename LA::P& pa, const typename LB::P& pb, const
   // split-bf16 only where it pays and is well conditioned: small problems (adapters, heads: < 1 GFLOP) and launches the
   // caller marks exact (the stem convolution: an all-positive input makes its weight gradient a cancelling sum) stay fp32
   const bool split = gemm_precision_mode() == 1 && !force_fp32 && 2.0 * M * N * (double)K >= 1073741824.0;
-  if (split)
-    hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
-  else
+  if (split) {
+    if constexpr (WM == 2 && WN == 2) {
+      if (pipelined_enabled())
+        hipLaunchKernelGGL((gemm_x3p_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
+      else
+        hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
+    } else {
+      hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
+    }
+  } else
     hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
   CXRK_LAUNCH_CHECK();
   return splitk;  // >= 1: number of slabs actually written

@@ -22,8 +22,10 @@ namespace cxrk {
 
 constexpr unsigned VOFF_OOB = 0x80000000u;
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)0x80000000, 0x00020000);
+// `live` false = a descriptor of zero bytes: every load through it returns 0 and moves no data (the pipelined mainloop
+// issues the loads of tiles past the end of its K range that way instead of branching around them)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float* p, bool live = true) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, live ? (int)0x80000000 : 0, 0x00020000);
 }
 __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
   // bit_cast, not a conversion: the builtin returns a 128-bit scalar-like value, and converting THAT to a vector splats
@@ -82,8 +84,8 @@ struct DenseKC {
     for (int j = 0; j < NV; ++j)
       voff[j] = idx0 + r0 + j * 32 < p.rows ? (unsigned)(((r0 + j * 32) * ld + k4 * 4) * 4) : VOFF_OOB;
   }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + k0);
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV], bool live = true) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + k0, live);
     if (k0 + BK <= K) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) v[j] = bload4(rs, voff[j]);
@@ -118,8 +120,8 @@ struct DenseMC {
 #pragma unroll
     for (int j = 0; j < NV; ++j) voff[j] = ok ? (unsigned)(((kr0 + j * RPP) * ld + c4 * 4) * 4) : VOFF_OOB;
   }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + (long)k0 * ld_);
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV], bool live = true) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + (long)k0 * ld_, live);
     if (k0 + BK <= K) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) v[j] = bload4(rs, voff[j]);
@@ -180,10 +182,10 @@ struct ConvIm2colKC {
       } else { off[j] = 0; inv[j] = 0xffffffffu; hi0[j] = -(1 << 28); wi0[j] = 0; }
     }
   }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV], bool live = true) {
     if constexpr (TAPWISE) {
       if (k0 != knext) { const int tap = k0 / C; tc = k0 - tap * C; tr = tap / S; ts = tap - tr * S; }
-      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + ((long)(tr * W + ts) * C + tc));
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + ((long)(tr * W + ts) * C + tc), live);
       const int t = tr * S + ts;
 #pragma unroll
       for (int j = 0; j < NV; ++j) v[j] = bload4(rs, masked_off(off[j], inv[j], t));
@@ -191,7 +193,7 @@ struct ConvIm2colKC {
       if (tc >= C) { tc = 0; if (++ts == S) { ts = 0; ++tr; } }
       knext = k0 + BK;
     } else {
-      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp);
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp, live);
       const int k = k0 + k4 * 4;
       const int tap = k / C, c = k - tap * C;
       const int r = tap / S, s = tap - r * S;
@@ -240,9 +242,9 @@ struct ConvDgradKC {
       } else { off[j] = 0; inv[j] = 0xffffffffu; }
     }
   }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV], bool live = true) {
     if (k0 != knext) { const int tap = k0 / Ko; tk = k0 - tap * Ko; tr = tap / S; ts = tap - tr * S; }
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + ((long)((R - 1 - tr) * Wo + (S - 1 - ts)) * Ko + tk));
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + ((long)((R - 1 - tr) * Wo + (S - 1 - ts)) * Ko + tk), live);
     const int t = tr * S + ts;
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] = bload4(rs, masked_off(off[j], inv[j], t));
@@ -275,9 +277,9 @@ struct ConvFilterMC {
 #pragma unroll
     for (int j = 0; j < NV; ++j) voff[j] = ok ? (unsigned)(((kr0 + j * RPP) * (int)RSC + c4 * 4) * 4) : VOFF_OOB;
   }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV], bool live = true) {
     if (k0 != knext) { tap = k0 / Ko; tk = k0 - tap * Ko; }
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + ((long)tk * RSC + (long)tap * C));
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + ((long)tk * RSC + (long)tap * C), live);
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] = bload4(rs, voff[j]);
     tk += BK;
@@ -323,11 +325,11 @@ struct ConvDgradS2KC {
       } else { off[j] = 0; inv[j] = 0xffffffffu; }
     }
   }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV], bool live = true) {
     if (k0 != knext) { ti = k0 / Ko; tk = k0 - ti * Ko; }
     const int ir = ti / t.ns, is = ti - ir * t.ns;
     const int dr = ir == 0 ? t.dr[0] : t.dr[1], ds = is == 0 ? t.ds[0] : t.ds[1];
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + ((long)(dr * Wo + ds) * Ko + tk));
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + ((long)(dr * Wo + ds) * Ko + tk), live);
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] = bload4(rs, masked_off(off[j], inv[j], ti));
     tk += BK;
@@ -358,11 +360,11 @@ struct ConvFilterS2MC {
 #pragma unroll
     for (int j = 0; j < NV; ++j) voff[j] = ok ? (unsigned)(((kr0 + j * RPP) * (int)RSC + c4 * 4) * 4) : VOFF_OOB;
   }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV], bool live = true) {
     if (k0 != knext) { ti = k0 / Ko; tk = k0 - ti * Ko; }
     const int ir = ti / t.ns, is = ti - ir * t.ns;
     const int tap = (ir == 0 ? t.r[0] : t.r[1]) * S + (is == 0 ? t.s[0] : t.s[1]);
-    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + ((long)tk * RSC + (long)tap * C));
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + ((long)tk * RSC + (long)tap * C), live);
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] = bload4(rs, voff[j]);
     tk += BK;
@@ -423,11 +425,11 @@ struct ConvIm2colMC {
       pwo[j] = k % Wo; const int t = k / Wo; pho[j] = t % Ho; pn[j] = t / Ho;
     }
   }
-  __device__ __forceinline__ void load(int k0, float4 (&v)[NV]) {
+  __device__ __forceinline__ void load(int k0, float4 (&v)[NV], bool live = true) {
     if (k0 != knext) seek(k0);
     const bool tail = k0 + BK > K;
     if (linear) {
-      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(x + ((long)k0 * C - bias));
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(x + ((long)k0 * C - bias), live);
       if (!halo && !tail) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) v[j] = bload4(rs, voff[j]);
@@ -440,7 +442,7 @@ struct ConvIm2colMC {
         }
       }
     } else {
-      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(x + (long)un * H * W * C);
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(x + (long)un * H * W * C, live);
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         const int hi = pho[j] * st + dh, wi = pwo[j] * st + dw;

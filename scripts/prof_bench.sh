@@ -1,0 +1,6 @@
+#!/bin/bash
+# rocprofv3 kernel statistics of a short bench run: prof_bench.sh <outdir> [bench args...]
+set -u
+OUT=$1; shift; R=$GRAFT_REPO_ROOT; mkdir -p $R/$OUT
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o prof --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --no-secondary --no-cpu-baseline "$@" > $R/$OUT/bench.log 2>&1
