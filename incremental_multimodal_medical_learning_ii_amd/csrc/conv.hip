@@ -344,10 +344,10 @@ extern "C" int cxrk_conv_bn_act_fwd(const float* x, const float* w_scaled, const
   } else {
     if (Ko <= 64) {
       ConvIm2colKC<256, false>::P pa{x, g, M, K}; DenseKC<64>::P pb{w_scaled, (long)K, Ko, K};
-      rc = launch_gemm<ConvIm2colKC<256, false>, DenseKC<64>, 4, 1>(pa, pb, ep, M, Ko, K, 1, stream, C <= 4);
+      rc = launch_gemm<ConvIm2colKC<256, false>, DenseKC<64>, 4, 1>(pa, pb, ep, M, Ko, K, 1, stream);
     } else {
       ConvIm2colKC<128, false>::P pa{x, g, M, K}; DenseKC<128>::P pb{w_scaled, (long)K, Ko, K};
-      rc = launch_gemm<ConvIm2colKC<128, false>, DenseKC<128>, 2, 2>(pa, pb, ep, M, Ko, K, 1, stream, C <= 4);
+      rc = launch_gemm<ConvIm2colKC<128, false>, DenseKC<128>, 2, 2>(pa, pb, ep, M, Ko, K, 1, stream);
     }
   }
   return rc < 0 ? rc : CXRK_OK;

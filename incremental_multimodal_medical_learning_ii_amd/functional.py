@@ -165,6 +165,12 @@ def _all_gather_cat(t: torch.Tensor, group) -> torch.Tensor:
     import torch.distributed as dist
     ws = dist.get_world_size(group)
     out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no GPU all-gather: stage through the host (rehearsals of the N>1 path on one GPU; RCCL takes the line below)
+        host = torch.empty(out.shape, dtype=t.dtype)
+        dist.all_gather_into_tensor(host, t.detach().cpu().contiguous(), group=group)
+        out.copy_(host)
+        return out
     dist.all_gather_into_tensor(out, t.contiguous(), group=group)
     return out
 

@@ -224,7 +224,7 @@ def conv_fwd(x, w_scaled, shift, residual, y, N, H, W, C, Ko, R, S, stride, pad,
     if profiler.on:
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         fl = 2.0 * N * Ho * Wo * Ko * R * S * C
-        ev = profiler.bracket(f"{_kern(fl, C <= 4)}<ConvIm2colKC,DenseKC,{'4,1' if Ko <= 64 else '2,2'}>", fl)
+        ev = profiler.bracket(f"{_kern(fl)}<ConvIm2colKC,DenseKC,{'4,1' if Ko <= 64 else '2,2'}>", fl)
     rc = lib.cxrk_conv_bn_act_fwd(_p(_chk(x, "conv.x")), _p(w_scaled), _p(shift), _p(residual), _p(y), N, H, W, C, Ko,
                                   R, S, stride, pad, int(relu), _stream())
     if ev is not None:

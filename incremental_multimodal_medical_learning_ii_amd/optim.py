@@ -32,7 +32,14 @@ class _FlatOptimizer:
                 raise ValueError("all parameters must be fp32 on one device")
         self.params = plist
         self.param_groups = [{"params": plist, "lr": lr}]
-        order = sorted(range(len(plist)), key=lambda i: plist[i].data_ptr())
+        # Layout of the flat buffers: parameter-list order, except that tensors sharing one storage (the fused q/k/v
+        # projections) stay together in storage order.  It must NOT depend on allocation addresses: every data-parallel
+        # rank has to lay its buffers out identically, or the flat all-reduce adds gradients of different tensors
+        # (tests/test_dist_gpu.py caught exactly that with an address-sorted layout).
+        groups: dict = {}
+        for i, p in enumerate(plist):
+            groups.setdefault(p.untyped_storage().data_ptr(), []).append(i)
+        order = [i for idxs in groups.values() for i in sorted(idxs, key=lambda j: plist[j].storage_offset())]
         offs, total = {}, 0
         for i in order:
             offs[i] = total
