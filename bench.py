@@ -124,13 +124,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    # Rehearsal knobs (never set by the driver): CXRK_DIST_BACKEND=gloo + CXRK_BENCH_DEVICE=0 run the N>1 code path with
+    # several ranks on ONE GPU (RCCL refuses two ranks per device), e.g. on the single-GPU test box.
+    backend = os.environ.get("CXRK_DIST_BACKEND", "nccl")
+    dev_index = int(os.environ.get("CXRK_BENCH_DEVICE", local_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: using {world} rank(s)", file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     from incremental_multimodal_medical_learning_ii_amd import kernels as K

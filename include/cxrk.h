@@ -39,6 +39,9 @@ extern "C" {
  * bwd:  dX = dY W               -> transA=0, transB=0 ;  dW = dY^T X -> transA=1, transB=0 (split-K)
  */
 size_t cxrk_gemm_splitk_ws_bytes(int M, int N, int splitk);
+/* Split-K factor the library recommends for a weight-gradient shaped GEMM (M x N output, K = rows reduced over): enough
+ * slabs to fill the chip with the tile the launch will take in the current precision mode. */
+int cxrk_gemm_wgrad_splitk(int M, int N, int K);
 int cxrk_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                   float* C, long ldc, const float* bias, const float* R, long ldr, const float* aux, long ldaux,
                   int auxmode, float* C2, long ldc2, int act, float alpha, int accumulate, int splitk, float* ws,

@@ -61,6 +61,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_sgd": (I, [P, P, L, F, F, F, P]),
     "cxrk_weight_reset_ws_bytes": (Z, []),
     "cxrk_weight_reset": (I, [P, P, L, F, P, P, Z, P]),
+    "cxrk_gemm_wgrad_splitk": (I, [I, I, I]),
     "cxrk_set_precision": (I, [I]),
     "cxrk_get_precision": (I, []),
     "cxrk_version": (c_char_p, []),

@@ -333,7 +333,10 @@ extern "C" int cxrk_conv_bn_act_fwd(const float* x, const float* w_scaled, const
   ep.C = y; ep.ldc = Ko; ep.bias = shift; ep.R = residual; ep.ldr = Ko; ep.act = relu ? 1 : 0; ep.alpha = 1.f;
   int rc;
   const bool tapwise = (C % BK == 0) && R * S <= 32;  // a K-tile inside one filter tap (everything but the stem)
-  if (tapwise) {
+  if (tapwise && use_wide256(M, Ko, K, 1, false, WIDE_MINK_FPROP)) {
+    ConvIm2colKC<256, true, NT_WIDE>::P pa{x, g, M, K}; DenseKC<256, NT_WIDE>::P pb{w_scaled, (long)K, Ko, K};
+    rc = launch_gemm_wide<ConvIm2colKC<256, true, NT_WIDE>, DenseKC<256, NT_WIDE>>(pa, pb, ep, M, Ko, K, 1, stream);
+  } else if (tapwise) {
     if (Ko <= 64) {
       ConvIm2colKC<256>::P pa{x, g, M, K}; DenseKC<64>::P pb{w_scaled, (long)K, Ko, K};
       rc = launch_gemm<ConvIm2colKC<256>, DenseKC<64>, 4, 1>(pa, pb, ep, M, Ko, K, 1, stream);
@@ -354,14 +357,25 @@ extern "C" int cxrk_conv_bn_act_fwd(const float* x, const float* w_scaled, const
 }
 
 // dx[n][hi][wi][c] = mask( sum_{r,s,ko} dy[n][(hi+pad-r)/st][(wi+pad-s)/st][ko] * w_scaled[ko][r][s][c] + residual )
-static int dgrad_tiles(int rows, int C) { return ceil_div(rows, C <= 64 ? 256 : 128) * (C <= 64 ? 4 : 2); }
+// 64-row slabs of partial sums one data-gradient launch writes: its row tile (256 with the 256x256 / 256x64 tiles, else 128)
+// rounded up, in slabs.  K = contraction length of that launch (selects the tile exactly as the launch does).
+static int dgrad_tiles(int rows, int C, long K) {
+  const bool t256 = use_wide256(rows, C, K, 1, false, WIDE_MINK_DGRAD) || C <= 64;
+  return ceil_div(rows, t256 ? 256 : 128) * (t256 ? 4 : 2);
+}
 
 // number of per-wave partial rows the fused BN reduction of a data-gradient launch produces (all parity classes)
-static long dgrad_bn_parts(int N, int H, int W, int C, int stride) {
-  if (stride == 1) return dgrad_tiles(N * H * W, C);
+static long dgrad_bn_parts(int N, int H, int W, int C, int stride, int Ko, int R, int S, int pad) {
+  if (stride == 1) return dgrad_tiles(N * H * W, C, (long)R * S * Ko);
   long t = 0;
   for (int ph = 0; ph < 2; ++ph)
-    for (int pw = 0; pw < 2; ++pw) { const int Hs = (H - ph + 1) / 2, Ws = (W - pw + 1) / 2; if (Hs > 0 && Ws > 0) t += dgrad_tiles(N * Hs * Ws, C); }
+    for (int pw = 0; pw < 2; ++pw) {
+      const int Hs = (H - ph + 1) / 2, Ws = (W - pw + 1) / 2;
+      int nr = 0, ns = 0;
+      for (int r = 0; r < R; ++r) if (((ph + pad - r) & 1) == 0) ++nr;
+      for (int q = 0; q < S; ++q) if (((pw + pad - q) & 1) == 0) ++ns;
+      if (Hs > 0 && Ws > 0 && nr > 0 && ns > 0) t += dgrad_tiles(N * Hs * Ws, C, (long)nr * ns * Ko);
+    }
   return t;
 }
 
@@ -381,7 +395,10 @@ static int conv_bwd_data_impl(const float* dy, const float* w_scaled, const floa
   ep.bn_part = bn_part; ep.bn_sub = bn_sub; ep.bn_ldsub = C; ep.bn_beta = bn_beta; ep.bn_beta2 = bn_beta2;
   int rc = 0;
   if (stride == 1) {
-    if (C <= 64) {
+    if (use_wide256(M, C, K, 1, false, WIDE_MINK_DGRAD)) {
+      ConvDgradKC<256, NT_WIDE>::P pa{dy, g, M, K}; ConvFilterMC<256, NT_WIDE>::P pb{w_scaled, g, C, K};
+      rc = launch_gemm_wide<ConvDgradKC<256, NT_WIDE>, ConvFilterMC<256, NT_WIDE>>(pa, pb, ep, M, C, K, 1, stream);
+    } else if (C <= 64) {
       ConvDgradKC<256>::P pa{dy, g, M, K}; ConvFilterMC<64>::P pb{w_scaled, g, C, K};
       rc = launch_gemm<ConvDgradKC<256>, ConvFilterMC<64>, 4, 1>(pa, pb, ep, M, C, K, 1, stream);
     } else {
@@ -420,9 +437,12 @@ static int conv_bwd_data_impl(const float* dy, const float* w_scaled, const floa
       if (Hs <= 0 || Ws <= 0 || t.nr == 0 || t.ns == 0) continue;
       const int Ms = N * Hs * Ws, Ks = t.nr * t.ns * Ko;
       EpiParams e2 = ep;
-      if (bn_part) { e2.bn_part = bn_part + part_off * 3 * C; part_off += dgrad_tiles(Ms, C); }
+      if (bn_part) { e2.bn_part = bn_part + part_off * 3 * C; part_off += dgrad_tiles(Ms, C, Ks); }
       e2.rm_on = 1; e2.rm_Hs = Hs; e2.rm_Ws = Ws; e2.rm_H = H; e2.rm_W = W; e2.rm_ph = ph; e2.rm_pw = pw;
-      if (C <= 64) {
+      if (use_wide256(Ms, C, Ks, 1, false, WIDE_MINK_DGRAD)) {
+        ConvDgradS2KC<256, NT_WIDE>::P pa{dy, g, t, Hs, Ws, Ms, Ks}; ConvFilterS2MC<256, NT_WIDE>::P pb{w_scaled, g, t, C, Ks};
+        rc = launch_gemm_wide<ConvDgradS2KC<256, NT_WIDE>, ConvFilterS2MC<256, NT_WIDE>>(pa, pb, e2, Ms, C, Ks, 1, stream);
+      } else if (C <= 64) {
         ConvDgradS2KC<256>::P pa{dy, g, t, Hs, Ws, Ms, Ks}; ConvFilterS2MC<64>::P pb{w_scaled, g, t, C, Ks};
         rc = launch_gemm<ConvDgradS2KC<256>, ConvFilterS2MC<64>, 4, 1>(pa, pb, e2, Ms, C, Ks, 1, stream);
       } else {
@@ -443,7 +463,13 @@ extern "C" int cxrk_conv_bn_act_bwd_data(const float* dy, const float* w_scaled,
 }
 
 extern "C" size_t cxrk_conv_bwd_data_bnsum_ws_bytes(int N, int H, int W, int C, int stride) {
-  return (size_t)(dgrad_bn_parts(N, H, W, C, stride) + 64) * 3 * C * sizeof(float);
+  // upper bound over the tile choices (the exact count needs the filter shape): 256-row tiles, 4 slabs each
+  long parts = 0;
+  if (stride == 1) parts = (long)ceil_div((long)N * H * W, 256) * 4;
+  else
+    for (int ph = 0; ph < 2; ++ph)
+      for (int pw = 0; pw < 2; ++pw) { const int Hs = (H - ph + 1) / 2, Ws = (W - pw + 1) / 2; if (Hs > 0 && Ws > 0) parts += (long)ceil_div((long)N * Hs * Ws, 256) * 4; }
+  return (size_t)(parts + 64) * 3 * C * sizeof(float);
 }
 
 // Data gradient + the BatchNorm-backward channel sums of the unit that PRODUCED relu_src, in one pass:
@@ -456,7 +482,7 @@ extern "C" int cxrk_conv_bn_act_bwd_data_bnsum(const float* dy, const float* w_s
                                                hipStream_t stream) {
   CXRK_CHECK_ARG(relu_src && bn_beta && sums && aligned16(bn_beta) && (!bn_beta2 || aligned16(bn_beta2)) && (!bn_sub || aligned16(bn_sub)));
   CXRK_CHECK_ARG(!(R == 1 && stride == 2));
-  const long np = dgrad_bn_parts(N, H, W, C, stride);
+  const long np = dgrad_bn_parts(N, H, W, C, stride, Ko, R, S, pad);
   if (ws == nullptr || ws_bytes < (size_t)(np + 64) * 3 * C * sizeof(float)) return CXRK_ERR_WS;
   const int rc = conv_bwd_data_impl(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R, S, stride, pad, ws, bn_sub, bn_beta,
                                     bn_beta2, stream);
@@ -474,15 +500,7 @@ extern "C" int cxrk_conv_bn_act_bwd_data_bnsum(const float* dy, const float* w_s
   return CXRK_OK;
 }
 
-static int wgrad_splitk(int Ko, int Ncols, long Kred) {
-  const int tiles = ceil_div(Ko, Ko <= 64 ? 64 : 128) * ceil_div(Ncols, Ko <= 64 ? 256 : 128);
-  long want = (1536 + tiles - 1) / tiles;            // ~6 blocks per CU
-  const long maxk = (Kred + 8 * BK - 1) / (8 * BK);  // at least 8 K-tiles per slab
-  if (want > maxk) want = maxk;
-  if (want < 1) want = 1;
-  if (want > 2048) want = 2048;
-  return (int)want;
-}
+static int wgrad_splitk(int Ko, int Ncols, long Kred) { return cxrk_gemm_wgrad_splitk(Ko, Ncols, (int)Kred); }
 
 extern "C" size_t cxrk_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad) {
   const ConvGeom g = make_geom(N, H, W, C, Ko, R, S, stride, pad);
@@ -509,7 +527,10 @@ extern "C" int cxrk_conv_bn_act_bwd_params(const float* x, const float* dy, cons
   EpiParams ep{};
   ep.C = ws; ep.ldc = Nc; ep.alpha = 1.f; ep.slab_stride = (long)Ko * Nc;
   int rc;
-  if (Ko <= 64) {
+  if (use_wide256(Ko, Nc, Kred, sk, Cpad <= 4)) {
+    DenseMC<256, NT_WIDE>::P pa{dy, (long)Ko, Ko, Kred}; ConvIm2colMC<256, NT_WIDE>::P pb{x, g, Nc, Kred};
+    rc = launch_gemm_wide<DenseMC<256, NT_WIDE>, ConvIm2colMC<256, NT_WIDE>>(pa, pb, ep, Ko, Nc, Kred, sk, stream);
+  } else if (Ko <= 64) {
     DenseMC<64>::P pa{dy, (long)Ko, Ko, Kred}; ConvIm2colMC<256>::P pb{x, g, Nc, Kred};
     rc = launch_gemm<DenseMC<64>, ConvIm2colMC<256>, 1, 4>(pa, pb, ep, Ko, Nc, Kred, sk, stream, Cpad <= 4);
   } else {

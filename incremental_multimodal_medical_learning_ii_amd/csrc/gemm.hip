@@ -48,6 +48,27 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, 
 
 }  // namespace
 
+// Split-K factor for a weight-gradient shaped GEMM (small M x N output, very long K): enough slabs to fill the chip with
+// the tile the launch will use (256x256: about two rounds of 256 blocks; 128x128: about six blocks per CU), each slab at
+// least 8 K-tiles long.
+extern "C" int cxrk_gemm_wgrad_splitk(int M, int N, int K) {
+  const long maxk = K / (8 * BK) > 0 ? K / (8 * BK) : 1;
+  if (gemm_precision_mode() == 1 && wide_mode() != 0 && M >= 256 && N >= 256) {
+    const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256);
+    long sk = (512 + tiles / 2) / tiles;
+    if (sk > maxk) sk = maxk;
+    if (sk < 1) sk = 1;
+    if (sk > 512) sk = 512;
+    if (use_wide256(M, N, K, (int)sk)) return (int)sk;
+  }
+  const long tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
+  long sk = (1536 + tiles - 1) / tiles;
+  if (sk > K / 256) sk = K / 256;
+  if (sk > 512) sk = 512;
+  if (sk < 1) sk = 1;
+  return (int)sk;
+}
+
 extern "C" size_t cxrk_gemm_splitk_ws_bytes(int M, int N, int splitk) {
   return splitk > 1 ? (size_t)splitk * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
@@ -76,8 +97,12 @@ extern "C" int cxrk_gemm_f32(int transA, int transB, int M, int N, int K, const 
     ep.C2 = C2; ep.ldc2 = ldc2; ep.act = act;
   }
   int rc;
+  // 256x256 tile: only for plain epilogues (weight gradients, split-K slabs).  With a fused bias / GELU / residual epilogue
+  // the one-block-per-CU kernel exposes it and the step's forward and data-gradient GEMMs ran 3-7 % slower than on 128x128.
 #define CXRK_TILES(LAT, LBT, pa_expr, pb_expr)                                                                    \
-  if (N <= 64) { LAT<256>::P pa = pa_expr; LBT<64>::P pb = pb_expr;                                               \
+  if ((plain || wide_mode() == 2) && use_wide256(M, N, K, splitk)) { LAT<256, NT_WIDE>::P pa = pa_expr; LBT<256, NT_WIDE>::P pb = pb_expr;       \
+    rc = launch_gemm_wide<LAT<256, NT_WIDE>, LBT<256, NT_WIDE>>(pa, pb, ep, M, N, K, splitk, stream); }           \
+  else if (N <= 64) { LAT<256>::P pa = pa_expr; LBT<64>::P pb = pb_expr;                                               \
     rc = launch_gemm<LAT<256>, LBT<64>, 4, 1>(pa, pb, ep, M, N, K, splitk, stream); }                             \
   else if (M <= 64) { LAT<64>::P pa = pa_expr; LBT<256>::P pb = pb_expr;                                          \
     rc = launch_gemm<LAT<64>, LBT<256>, 1, 4>(pa, pb, ep, M, N, K, splitk, stream); }                             \

@@ -41,6 +41,7 @@ struct EpiParams {
   // optional output-row remap (stride-2 dgrad parity classes): GEMM row (n,a,b) -> pixel (n, 2a+ph, 2b+pw) of [N,H,W]
   int rm_on, rm_Hs, rm_Ws, rm_H, rm_W, rm_ph, rm_pw;
   int vec;  // set by launch_gemm: every pointer / leading dimension allows 16-byte row accesses
+  int nt;   // set by launch_gemm: store C non-temporally (large outputs)
   // optional fused BatchNorm-backward reductions over the rows of this launch (needs auxmode 1, vec): with v the stored
   // value and y = aux,   S0[c] = sum v,   S1[c] = sum v*(y - sub - beta[c]),   S2[c] = sum v*(sub - beta2[c]).
   // Per-wave partials go to bn_part[(mt*WM + wm)][3][N]; a second kernel adds them up (deterministic).
@@ -123,20 +124,19 @@ namespace cxrk {
 // Epilogue shared by the fp32 and the split-bf16 mainloops (both MFMA shapes have the same 32x32 C/D map).
 // `smem` = at least 4 * 32 * 64 floats of LDS that no wave reads any more.
 // ---------------------------------------------------------------------------------------------------------------
-template <int WM, int WN>
-__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const EpiParams& ep, float* smem, int M, int N, int m0,
-                                              int n0, int mt, int z, int wave, int lane) {
-  const int wm = wave / WN, wn = wave % WN;
+// One wave's 64x64 sub-tile: rows row0.., columns col0..; `st` = this wave's 32x64-float staging area in LDS;
+// `part` = index of this 64-row slab among the fused BatchNorm partial sums (row0 / 64 over the padded row range).
+__device__ __forceinline__ void gemm_epilogue64(f32x16 (&acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0,
+                                                int col0, int part, int z, int lane) {
   const int r = lane & 31, h = lane >> 5;
   // Epilogue.  C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), i.e. a
   // lane owns ONE column — stored straight from the accumulators that is 64 dword stores per lane in 128-B pieces.
   // Instead each wave transposes its 64x64 sub-tile through the (now free) operand LDS in two 32-row passes and
   // leaves with 16 B per lane: 16 float4 stores per lane, 256 contiguous bytes per row, and the residual / mask /
   // GELU' side inputs are read the same way.  This is what the HBM-bound shapes (1x1 convolutions with K = 64) pay for.
-  float* const st = smem + wave * (32 * 64);
   float* C = ep.C + (long)z * ep.slab_stride;
   const int c4 = lane & 15, rq = lane >> 4;
-  const int col = n0 + wn * 64 + c4 * 4;
+  const int col = col0 + c4 * 4;
   float4 bv = zero4();
   if (ep.bias && col < N) {
     if (ep.vec) bv = *reinterpret_cast<const float4*>(ep.bias + col);
@@ -159,7 +159,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const EpiPara
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int rl = t * 4 + rq;
-      const int grow = m0 + wm * 64 + i * 32 + rl;
+      const int grow = row0 + i * 32 + rl;
       float4 v4 = *reinterpret_cast<const float4*>(st + rl * 64 + c4 * 4);
       if (grow >= M || col >= N) continue;
       long row = grow;
@@ -195,7 +195,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const EpiPara
             }
           }
         }
-        *reinterpret_cast<float4*>(C + row * ep.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+        if (ep.nt) { const f32x4 o = {v[0], v[1], v[2], v[3]}; __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(C + row * ep.ldc + col)); }
+        else *reinterpret_cast<float4*>(C + row * ep.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -224,11 +225,18 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const EpiPara
         bs[k][q] = t;
       }
     if (rq == 0 && col < N) {
-      float* dst = ep.bn_part + ((long)(mt * WM + wm) * 3) * N + col;
+      float* dst = ep.bn_part + ((long)part * 3) * N + col;
 #pragma unroll
       for (int k = 0; k < 3; ++k) *reinterpret_cast<float4*>(dst + (long)k * N) = make_float4(bs[k][0], bs[k][1], bs[k][2], bs[k][3]);
     }
   }
+}
+
+template <int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const EpiParams& ep, float* smem, int M, int N, int m0,
+                                              int n0, int mt, int z, int wave, int lane) {
+  const int wm = wave / WN, wn = wave % WN;
+  gemm_epilogue64(acc, ep, smem + wave * (32 * 64), M, N, m0 + wm * 64, n0 + wn * 64, mt * WM + wm, z, lane);
 }
 
 // XCD-aware tile mapping (speed only, never correctness).  Workgroups are dealt round-robin over the 8 XCDs, so blocks b
@@ -437,87 +445,63 @@ __global__ __launch_bounds__(NTHREADS, (WM == 2 && WN == 2) ? 3 : 2) void gemm_x
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Software-pipelined split-bf16 mainloop (128x128 tile).  The single-buffer kernel above runs its phases one after the
-// other -- MFMA block, barrier, convert + LDS store, barrier, global loads -- and the co-resident blocks of a CU fall into
-// lockstep, so the matrix pipe idles through every staging phase (SQ_VALU_MFMA_BUSY_CYCLES 30 %, SQ_WAIT_ANY 38 %).
-// Here a K-tile is ONE phase: two LDS buffers, tile t+1 is converted and stored into the other buffer between the MFMAs
-// of tile t, the loads of tile t+2 are issued behind them, and a single barrier closes the tile.
+// 256x256 split-bf16 mainloop: 512 threads = 8 waves as 2 (M) x 4 (N), 128x64 outputs per wave (4x2 MFMA tiles, 128
+// accumulator registers), one block per CU, two LDS buffers (2 x 80 KB = all of the CU's LDS).
+// Against the 128x128 tile every per-MFMA overhead of the loop is smaller: operand bytes through L1 and the
+// convert + LDS-store work per MFMA are halved ((BM + BN) / (BM * BN)), fragment reads drop from 8 to 6 per 12 MFMAs.
+// With one block per CU nothing else hides a phase, so the K-tile is a single software-pipelined phase: A(t+1) is
+// converted and stored beside the first half of the MFMAs of tile t and its registers are re-loaded with A(t+2) at once,
+// the same for B beside the second half; one barrier per K-tile.
 // ---------------------------------------------------------------------------------------------------------------
-#ifndef CXRK_PIPE_SCHED
-#define CXRK_PIPE_SCHED 1
-#endif
+constexpr int NT_WIDE = 512;
+
 template <class LA, class LB>
-__device__ __forceinline__ void x3_mfma_block(const unsigned short* Ahi, const unsigned short* Alo, const unsigned short* Bhi,
-                                              const unsigned short* Blo, int wm, int wn, int kc, int lane, f32x16 (&acc)[2][2]) {
-  bf16x8 ah[2], al[2], bh[2], bl[2];
+__device__ __forceinline__ void x3w_mfma_block(const unsigned short* Ahi, const unsigned short* Alo, const unsigned short* Bhi,
+                                               const unsigned short* Blo, int wm, int wn, int kc, int lane,
+                                               f32x16 (&acc0)[2][2], f32x16 (&acc1)[2][2]) {
+  bf16x8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if constexpr (LA::KC) {
-      ah[i] = frag_kc(Ahi, wm * 64 + i * 32, kc, lane); al[i] = frag_kc(Alo, wm * 64 + i * 32, kc, lane);
-    } else {
-      ah[i] = frag_mc<LA::LDT>(Ahi, wm * 64 + i * 32, kc, lane); al[i] = frag_mc<LA::LDT>(Alo, wm * 64 + i * 32, kc, lane);
-    }
+  for (int j = 0; j < 2; ++j) {
     if constexpr (LB::KC) {
-      bh[i] = frag_kc(Bhi, wn * 64 + i * 32, kc, lane); bl[i] = frag_kc(Blo, wn * 64 + i * 32, kc, lane);
+      bh[j] = frag_kc(Bhi, wn * 64 + j * 32, kc, lane); bl[j] = frag_kc(Blo, wn * 64 + j * 32, kc, lane);
     } else {
-      bh[i] = frag_mc<LB::LDT>(Bhi, wn * 64 + i * 32, kc, lane); bl[i] = frag_mc<LB::LDT>(Blo, wn * 64 + i * 32, kc, lane);
+      bh[j] = frag_mc<LB::LDT>(Bhi, wn * 64 + j * 32, kc, lane); bl[j] = frag_mc<LB::LDT>(Blo, wn * 64 + j * 32, kc, lane);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (LA::KC) {
+      ah[i] = frag_kc(Ahi, wm * 128 + i * 32, kc, lane); al[i] = frag_kc(Alo, wm * 128 + i * 32, kc, lane);
+    } else {
+      ah[i] = frag_mc<LA::LDT>(Ahi, wm * 128 + i * 32, kc, lane); al[i] = frag_mc<LA::LDT>(Alo, wm * 128 + i * 32, kc, lane);
     }
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc0[i][j], 0, 0, 0);
+      acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc0[i][j], 0, 0, 0);
+      acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc0[i][j], 0, 0, 0);
+    }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[2 + i], bh[j], acc1[i][j], 0, 0, 0);
+      acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[2 + i], bl[j], acc1[i][j], 0, 0, 0);
+      acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[2 + i], bh[j], acc1[i][j], 0, 0, 0);
     }
 }
 
-// One K-tile of the pipelined loop.  (rc_a, rc_b) hold tile t+1 (loaded a whole tile ago), (rn_a, rn_b) receive tile t+2;
-// `cur` / `nxt` are the LDS buffers of tile t / t+1.  Stores and loads are unconditional -- past the end of the K range the
-// loads go through a zero-byte descriptor and the stores write zeros nobody reads -- so the body is one basic block and
-// the scheduler can lay the conversion and the LDS writes between the MFMAs (sched_group_barrier pattern below).
 template <class LA, class LB>
-__device__ __forceinline__ void x3p_tile(LA& la, LB& lb, float4 (&rc_a)[LA::NV], float4 (&rc_b)[LB::NV], float4 (&rn_a)[LA::NV],
-                                         float4 (&rn_b)[LB::NV], const unsigned short* cur, unsigned short* nxt, int k0, int kend,
-                                         int wm, int wn, int lane, f32x16 (&acc)[2][2]) {
-  constexpr int PLANE_A = LA::PLANE, PLANE_B = LB::PLANE;
-  const bool has2 = (k0 + 2 * BK < kend) && !(CXRK_ABL & 1);   // CXRK_ABL: tuning-harness ablations, 0 in the library
-  la.load(k0 + 2 * BK, rn_a, has2); lb.load(k0 + 2 * BK, rn_b, has2);
-  if (!(CXRK_ABL & 2)) la.store2(nxt, nxt + PLANE_A, rc_a);
-  x3_mfma_block<LA, LB>(cur, cur + PLANE_A, cur + 2 * PLANE_A, cur + 2 * PLANE_A + PLANE_B, wm, wn, 0, lane, acc);
-#if CXRK_PIPE_SCHED
-  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // fragment reads of the first half
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-  }
-#endif
-  if (!(CXRK_ABL & 2)) lb.store2(nxt + 2 * PLANE_A, nxt + 2 * PLANE_A + PLANE_B, rc_b);
-  x3_mfma_block<LA, LB>(cur, cur + PLANE_A, cur + 2 * PLANE_A, cur + 2 * PLANE_A + PLANE_B, wm, wn, 1, lane, acc);
-#if CXRK_PIPE_SCHED
-  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-  }
-#endif
-  __syncthreads();
-}
-
-template <class LA, class LB, int WM, int WN>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_x3p_kernel(typename LA::P pa, typename LB::P pb, EpiParams ep,
-                                                               int M, int N, int K, int nMt, int nNt, int kchunk) {
-  constexpr int BM = WM * 64, BN = WN * 64;
+__global__ __launch_bounds__(NT_WIDE, 1) void gemm_x3w_kernel(typename LA::P pa, typename LB::P pb, EpiParams ep,
+                                                              int M, int N, int K, int nMt, int nNt, int kchunk) {
+  constexpr int BM = 256, BN = 256;
   constexpr int PLANE_A = LA::PLANE, PLANE_B = LB::PLANE;  // halfwords
-  constexpr int BUF = 2 * (PLANE_A + PLANE_B);            // halfwords of one buffer (hi + lo planes of both operands)
-  static_assert(BUF * 2 >= 4 * 32 * 64 * 4, "operand LDS too small to stage the epilogue");
+  constexpr int BUF = 2 * (PLANE_A + PLANE_B);
+  static_assert(2 * BUF * 2 <= 160 * 1024, "two buffers must fit the CU's LDS");
+  static_assert(BUF * 2 >= 8 * 32 * 64 * 4, "operand LDS too small to stage the epilogue");
   __shared__ __attribute__((aligned(16))) unsigned short smem16[2 * BUF];
 
   int mt, nt;
@@ -529,41 +513,93 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_x3p_kernel(typename LA::P pa
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = wave >> 2, wn = wave & 3;
 
   LA la; LB lb;
   la.init(pa, m0, tid);
   lb.init(pb, n0, tid);
 
-  f32x16 acc[2][2];
+  f32x16 acc0[2][2], acc1[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
 
-  // two register sets: set 0 = tiles 0, 2, 4, ..., set 1 = tiles 1, 3, 5, ...
-  float4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];
-  la.load(kbeg, ra0, kbeg < kend); lb.load(kbeg, rb0, kbeg < kend);
-  la.load(kbeg + BK, ra1, kbeg + BK < kend); lb.load(kbeg + BK, rb1, kbeg + BK < kend);
-  la.store2(smem16, smem16 + PLANE_A, ra0); lb.store2(smem16 + 2 * PLANE_A, smem16 + 2 * PLANE_A + PLANE_B, rb0);
+  float4 ra[LA::NV], rb[LB::NV];
+  la.load(kbeg, ra, kbeg < kend); lb.load(kbeg, rb, kbeg < kend);
+  la.store2(smem16, smem16 + PLANE_A, ra); lb.store2(smem16 + 2 * PLANE_A, smem16 + 2 * PLANE_A + PLANE_B, rb);
+  la.load(kbeg + BK, ra, kbeg + BK < kend); lb.load(kbeg + BK, rb, kbeg + BK < kend);
   __syncthreads();
 
-  for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
-    x3p_tile<LA, LB>(la, lb, ra1, rb1, ra0, rb0, smem16, smem16 + BUF, k0, kend, wm, wn, lane, acc);
-    if (k0 + BK >= kend) break;
-    x3p_tile<LA, LB>(la, lb, ra0, rb0, ra1, rb1, smem16 + BUF, smem16, k0 + BK, kend, wm, wn, lane, acc);
+  int cur = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const unsigned short* c = smem16 + cur * BUF;
+    unsigned short* n = smem16 + (cur ^ 1) * BUF;
+    const bool has2 = (k0 + 2 * BK < kend) && !(CXRK_ABL & 1);
+    if (!(CXRK_ABL & 2)) la.store2(n, n + PLANE_A, ra);          // A(t+1): registers -> the other buffer ...
+    la.load(k0 + 2 * BK, ra, has2);                               // ... and re-load them with A(t+2) at once
+    x3w_mfma_block<LA, LB>(c, c + PLANE_A, c + 2 * PLANE_A, c + 2 * PLANE_A + PLANE_B, wm, wn, 0, lane, acc0, acc1);
+    if (!(CXRK_ABL & 2)) lb.store2(n + 2 * PLANE_A, n + 2 * PLANE_A + PLANE_B, rb);
+    lb.load(k0 + 2 * BK, rb, has2);
+    x3w_mfma_block<LA, LB>(c, c + PLANE_A, c + 2 * PLANE_A, c + 2 * PLANE_A + PLANE_B, wm, wn, 1, lane, acc0, acc1);
+    __syncthreads();
+    cur ^= 1;
   }
-  if ((CXRK_ABL & 4) && acc[0][0][0] != 12345.678f) return;
-  gemm_epilogue<WM, WN>(acc, ep, reinterpret_cast<float*>(smem16), M, N, m0, n0, mt, z, wave, lane);
+  if ((CXRK_ABL & 4) && acc0[0][0][0] != 12345.678f) return;
+  float* st = reinterpret_cast<float*>(smem16) + wave * (32 * 64);
+  gemm_epilogue64(acc0, ep, st, M, N, m0 + wm * 128, n0 + wn * 64, mt * 4 + wm * 2, z, lane);
+  gemm_epilogue64(acc1, ep, st, M, N, m0 + wm * 128 + 64, n0 + wn * 64, mt * 4 + wm * 2 + 1, z, lane);
 }
 
 // 0 = exact fp32 MFMA (default), 1 = split-bf16.  Process-wide, set through cxrk_set_precision().
 inline int& gemm_precision_mode() { static int mode = 0; return mode; }
 
-// Tuning switch (environment CXRK_PIPE, read once; default on): the software-pipelined split-bf16 mainloop for 128x128 tiles.
-inline bool pipelined_enabled() { static const bool on = [] { const char* e = getenv("CXRK_PIPE"); return e && e[0] == '1'; }(); return on; }
+// Outputs that cannot stay in the 32 MiB of L2 anyway are stored non-temporally, so that they do not evict the operand
+// panels the co-running tiles are re-reading (dense 32768x3072x768: +10 % with the 256x256 tile).
+static inline int stream_output(int M, int N, int splitk) { return (double)M * N * 4.0 * (splitk > 1 ? splitk : 1) >= 64.0 * 1048576.0; }
+
+// 256x256-tile policy.  CXRK_WIDE (environment, read once): 0 = never, 1 (default) = where it pays, 2 = wherever the
+// precision mode allows it (test coverage on small shapes).  "Pays": split-bf16 launch, both tile dimensions filled, a K
+// loop long enough to amortise the exposed prologue / epilogue of a one-block-per-CU kernel, and a tile count that fills
+// the 256 CUs in whole rounds to at least 70 %.
+inline int wide_mode() { static const int m = [] { const char* e = getenv("CXRK_WIDE"); return e ? atoi(e) : 1; }(); return m; }
+// min_k: shortest K loop (per split-K slab) for which the caller's kind of launch gains (measured per kind on the step's
+// shapes, scripts/layer_table.py: the heavier the fused epilogue, the longer the loop has to be to pay for exposing it).
+constexpr long WIDE_MINK_PLAIN = 512;    // dense layers, weight gradients (plain / bias / GELU epilogues)
+constexpr long WIDE_MINK_FPROP = 2048;   // convolution forward (shift + residual + ReLU)
+constexpr long WIDE_MINK_DGRAD = 4096;   // convolution data gradient (ReLU mask + fused BatchNorm sums)
+static inline bool use_wide256(int M, int N, long K, int splitk, bool force_fp32 = false, long min_k = WIDE_MINK_PLAIN) {
+  if (gemm_precision_mode() != 1 || force_fp32 || 2.0 * M * N * (double)K < 1073741824.0) return false;
+  const int mode = wide_mode();
+  if (mode == 2) return true;
+  if (mode == 0 || M < 256 || N < 256) return false;
+  const long kper = splitk > 1 ? K / splitk : K;
+  if (kper < min_k) return false;
+  const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256) * (splitk > 1 ? splitk : 1);
+  const long rounds = (tiles + 255) / 256;
+  return tiles * 10 >= rounds * 256 * 7;
+}
+
+template <class LA, class LB>
+static int launch_gemm_wide(const typename LA::P& pa, const typename LB::P& pb, const EpiParams& ep, int M, int N, int K,
+                            int splitk, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return CXRK_ERR_ARG;
+  const int nMt = ceil_div(M, 256), nNt = ceil_div(N, 256);
+  int kchunk = K;
+  if (splitk > 1) { kchunk = ceil_div(ceil_div(K, splitk), BK) * BK; splitk = ceil_div(K, kchunk); }
+  else splitk = 1;
+  dim3 grid((unsigned)(nMt * nNt), (unsigned)splitk, 1);
+  EpiParams e = ep;
+  auto ok16 = [](const void* p_, long ld) { return p_ == nullptr || (aligned16(p_) && (ld % 4) == 0); };
+  e.vec = (N % 4 == 0) && ok16(e.C, e.ldc) && ((e.slab_stride % 4) == 0) && ok16(e.R, e.ldr) && ok16(e.aux, e.ldaux) &&
+          ok16(e.C2, e.ldc2) && (e.bias == nullptr || aligned16(e.bias));
+  e.nt = stream_output(M, N, splitk);
+  hipLaunchKernelGGL((gemm_x3w_kernel<LA, LB>), grid, dim3(NT_WIDE), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
+  CXRK_LAUNCH_CHECK();
+  return splitk;
+}
 
 // Host launcher.  splitk > 1 writes plain partial slabs (caller reduces them).
 template <class LA, class LB, int WM, int WN>
@@ -583,16 +619,10 @@ static int launch_gemm(const typename LA::P& pa, const typename LB::P& pb, const
   // split-bf16 only where it pays and is well conditioned: small problems (adapters, heads: < 1 GFLOP) and launches the
   // caller marks exact (the stem convolution: an all-positive input makes its weight gradient a cancelling sum) stay fp32
   const bool split = gemm_precision_mode() == 1 && !force_fp32 && 2.0 * M * N * (double)K >= 1073741824.0;
-  if (split) {
-    if constexpr (WM == 2 && WN == 2) {
-      if (pipelined_enabled())
-        hipLaunchKernelGGL((gemm_x3p_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
-      else
-        hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
-    } else {
-      hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
-    }
-  } else
+  e.nt = stream_output(M, N, splitk);
+  if (split)
+    hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
+  else
     hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
   CXRK_LAUNCH_CHECK();
   return splitk;  // >= 1: number of slabs actually written

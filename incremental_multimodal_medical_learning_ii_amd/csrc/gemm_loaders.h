@@ -41,19 +41,19 @@ __device__ __forceinline__ unsigned masked_off(unsigned off, unsigned inv, int t
 }
 
 // ---- LDS staging shared by the loaders -------------------------------------------------------------------------------
-// K-contiguous operand (k4 = tid & 7 -> 4 consecutive k, r0 = tid >> 3 -> row, +32 rows per j)
-template <int NV, int LD>
+// K-contiguous operand (k4 = tid & 7 -> 4 consecutive k, r0 = tid >> 3 -> row, +RP = NT / 8 rows per j)
+template <int NV, int LD, int RP>
 __device__ __forceinline__ void stage_kc(float* S, int r0, int k4, const float4 (&v)[NV]) {
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    float* d = S + (k4 * 4) * LD + r0 + j * 32;
+    float* d = S + (k4 * 4) * LD + r0 + j * RP;
     d[0] = v[j].x; d[LD] = v[j].y; d[2 * LD] = v[j].z; d[3 * LD] = v[j].w;
   }
 }
-template <int NV>
+template <int NV, int RP>
 __device__ __forceinline__ void stage2_kc(unsigned short* hi, unsigned short* lo, int r0, int k4, const float4 (&v)[NV]) {
 #pragma unroll
-  for (int j = 0; j < NV; ++j) store2_kc(hi, lo, r0 + j * 32, k4 * 4, v[j]);
+  for (int j = 0; j < NV; ++j) store2_kc(hi, lo, r0 + j * RP, k4 * 4, v[j]);
 }
 // idx-contiguous operand (c4 = tid % VPR -> 4 consecutive idx, kr0 = tid / VPR -> k row, +RPP rows per j)
 template <int NV, int LD, int RPP>
@@ -68,11 +68,12 @@ __device__ __forceinline__ void stage2_mc(unsigned short* hi, unsigned short* lo
 }
 
 // X(idx, k) = ptr[idx*ld + k]   (k contiguous)
-template <int TILE>
+template <int TILE, int NT = NTHREADS>
 struct DenseKC {
   static constexpr bool KC = true;
   static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
+  static constexpr int RP = NT / 8;   // rows per pass
+  static constexpr int NV = TILE / RP;
   static constexpr int LD = TILE + 1;  // LDS row stride (floats)
   struct P { const float* ptr; long ld; int rows; int K; };
   const float* bp; unsigned voff[NV]; int k4, r0, K;
@@ -82,7 +83,7 @@ struct DenseKC {
     const int ld = (int)p.ld;
 #pragma unroll
     for (int j = 0; j < NV; ++j)
-      voff[j] = idx0 + r0 + j * 32 < p.rows ? (unsigned)(((r0 + j * 32) * ld + k4 * 4) * 4) : VOFF_OOB;
+      voff[j] = idx0 + r0 + j * RP < p.rows ? (unsigned)(((r0 + j * RP) * ld + k4 * 4) * 4) : VOFF_OOB;
   }
   __device__ __forceinline__ void load(int k0, float4 (&v)[NV], bool live = true) {
     const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + k0, live);
@@ -95,20 +96,21 @@ struct DenseKC {
       for (int j = 0; j < NV; ++j) v[j] = bload4(rs, voff[j] | t);
     }
   }
-  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_kc<NV>(hi, lo, r0, k4, v); }
-  __device__ __forceinline__ void store(float* S, const float4 (&v)[NV]) const { stage_kc<NV, LD>(S, r0, k4, v); }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_kc<NV, RP>(hi, lo, r0, k4, v); }
+  __device__ __forceinline__ void store(float* S, const float4 (&v)[NV]) const { stage_kc<NV, LD, RP>(S, r0, k4, v); }
 };
 
 // X(idx, k) = ptr[k*ld + idx]   (idx contiguous)
-template <int TILE>
+template <int TILE, int NT = NTHREADS>
 struct DenseMC {
   static constexpr bool KC = false;
   static constexpr int LDT = TILE + 32;
   static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
+  
   static constexpr int LD = TILE + 4;  // LDS row stride (floats)
   static constexpr int VPR = TILE / 4;          // float4 per k-row
-  static constexpr int RPP = NTHREADS / VPR;    // k-rows per pass
+  static constexpr int RPP = NT / VPR;          // k-rows per pass
+  static constexpr int NV = BK / RPP;
   struct P { const float* ptr; long ld; int cols; int K; };
   const float* bp; long ld_; unsigned voff[NV];
   int c4, kr0, K;
@@ -144,11 +146,12 @@ struct ConvGeom {
 // fprop A operand: idx = (n,ho,wo), k = (r,s,c) -> x[n][ho*st-pad+r][wo*st-pad+s][c]   (c contiguous)
 // TAPWISE: C % BK == 0, so a K-tile lies inside ONE filter tap (r,s): the tap is wave-uniform state, the halo a bit mask
 // over the R*S <= 32 taps.  Otherwise (the stem: C = 4, 49 taps) every lane derives its own tap.
-template <int TILE, bool TAPWISE = true>
+template <int TILE, bool TAPWISE = true, int NT = NTHREADS>
 struct ConvIm2colKC {
   static constexpr bool KC = true;
   static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
+  static constexpr int RP = NT / 8;   // rows per pass
+  static constexpr int NV = TILE / RP;
   static constexpr int LD = TILE + 1;  // LDS row stride (floats)
   struct P { const float* x; ConvGeom g; int rows; int K; };
   const float* bp;
@@ -167,7 +170,7 @@ struct ConvIm2colKC {
     knext = -1; tr = ts = tc = 0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const int row = idx0 + r0 + j * 32;
+      const int row = idx0 + r0 + j * RP;
       if (row < p.rows) {
         const int wo = row % p.g.Wo; const int t = row / p.g.Wo; const int ho = t % p.g.Ho; const int n = t / p.g.Ho;
         const int h0 = ho * p.g.stride - p.g.pad, w0 = wo * p.g.stride - p.g.pad;
@@ -205,17 +208,18 @@ struct ConvIm2colKC {
       }
     }
   }
-  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_kc<NV>(hi, lo, r0, k4, v); }
-  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const { stage_kc<NV, LD>(Sm, r0, k4, v); }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_kc<NV, RP>(hi, lo, r0, k4, v); }
+  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const { stage_kc<NV, LD, RP>(Sm, r0, k4, v); }
 };
 
 // dgrad A operand (stride 1): idx = (n,hi,wi), k = (r,s,ko) -> dy[n][hi+pad-r][wi+pad-s][ko].  Ko % BK == 0: a K-tile
 // lies inside one tap.  Stride-2 layers go through ConvDgradS2KC.
-template <int TILE>
+template <int TILE, int NT = NTHREADS>
 struct ConvDgradKC {
   static constexpr bool KC = true;
   static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
+  static constexpr int RP = NT / 8;   // rows per pass
+  static constexpr int NV = TILE / RP;
   static constexpr int LD = TILE + 1;  // LDS row stride (floats)
   struct P { const float* dy; ConvGeom g; int rows; int K; };
   const float* bp; unsigned off[NV], inv[NV];
@@ -230,7 +234,7 @@ struct ConvDgradKC {
     knext = -1; tr = ts = tk = 0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const int row = idx0 + r0 + j * 32;
+      const int row = idx0 + r0 + j * RP;
       if (row < p.rows) {
         const int wi = row % W; const int t = row / W; const int hi = t % H; const int n = t / H;
         off[j] = (unsigned)(((((n - n_first) * Ho + hi + pad) * Wo + wi + pad) * Ko + k4 * 4) * 4);
@@ -252,20 +256,21 @@ struct ConvDgradKC {
     if (tk >= Ko) { tk = 0; if (++ts == S) { ts = 0; ++tr; } }
     knext = k0 + BK;
   }
-  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_kc<NV>(hi, lo, r0, k4, v); }
-  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const { stage_kc<NV, LD>(Sm, r0, k4, v); }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_kc<NV, RP>(hi, lo, r0, k4, v); }
+  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const { stage_kc<NV, LD, RP>(Sm, r0, k4, v); }
 };
 
 // dgrad B operand: k = (r,s,ko), idx = c -> w[ko][r][s][c]   (c contiguous)
-template <int TILE>
+template <int TILE, int NT = NTHREADS>
 struct ConvFilterMC {
   static constexpr bool KC = false;
   static constexpr int LDT = TILE + 32;
   static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
+  
   static constexpr int LD = TILE + 4;  // LDS row stride (floats)
   static constexpr int VPR = TILE / 4;
-  static constexpr int RPP = NTHREADS / VPR;
+  static constexpr int RPP = NT / VPR;
+  static constexpr int NV = BK / RPP;
   struct P { const float* w; ConvGeom g; int cols; int K; };
   const float* bp; unsigned voff[NV]; int c4, kr0, Ko, C; long RSC;
   int tap, tk, knext;
@@ -295,11 +300,12 @@ struct ConvFilterMC {
 // four classes).  idx = (n,a,b) on the half-resolution grid; k = (ti,ko) with ti indexing the class's tap list.
 struct S2Taps { int nr, ns; int r[2], s[2]; int dr[2], ds[2]; };  // ho = a + dr[tr], wo = b + ds[ts]   (dr, ds >= 0)
 
-template <int TILE>
+template <int TILE, int NT = NTHREADS>
 struct ConvDgradS2KC {
   static constexpr bool KC = true;
   static constexpr int PLANE = TILE * LDH;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
+  static constexpr int RP = NT / 8;   // rows per pass
+  static constexpr int NV = TILE / RP;
   static constexpr int LD = TILE + 1;  // LDS row stride (floats)
   struct P { const float* dy; ConvGeom g; S2Taps t; int Hs, Ws; int rows; int K; };
   const float* bp; unsigned off[NV], inv[NV];
@@ -313,7 +319,7 @@ struct ConvDgradS2KC {
     knext = -1; ti = tk = 0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const int row = idx0 + r0 + j * 32;
+      const int row = idx0 + r0 + j * RP;
       if (row < p.rows) {
         const int b = row % p.Ws; const int q = row / p.Ws; const int a = q % p.Hs; const int n = q / p.Hs;
         off[j] = (unsigned)(((((n - n_first) * Ho + a) * Wo + b) * Ko + k4 * 4) * 4);
@@ -336,19 +342,20 @@ struct ConvDgradS2KC {
     if (tk >= Ko) { tk = 0; ++ti; }
     knext = k0 + BK;
   }
-  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_kc<NV>(hi, lo, r0, k4, v); }
-  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const { stage_kc<NV, LD>(Sm, r0, k4, v); }
+  __device__ __forceinline__ void store2(unsigned short* hi, unsigned short* lo, const float4 (&v)[NV]) const { stage2_kc<NV, RP>(hi, lo, r0, k4, v); }
+  __device__ __forceinline__ void store(float* Sm, const float4 (&v)[NV]) const { stage_kc<NV, LD, RP>(Sm, r0, k4, v); }
 };
 
-template <int TILE>
+template <int TILE, int NT = NTHREADS>
 struct ConvFilterS2MC {
   static constexpr bool KC = false;
   static constexpr int LDT = TILE + 32;
   static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
+  
   static constexpr int LD = TILE + 4;  // LDS row stride (floats)
   static constexpr int VPR = TILE / 4;
-  static constexpr int RPP = NTHREADS / VPR;
+  static constexpr int RPP = NT / VPR;
+  static constexpr int NV = BK / RPP;
   struct P { const float* w; ConvGeom g; S2Taps t; int cols; int K; };
   const float* bp; unsigned voff[NV]; int c4, kr0, Ko, C, S; long RSC; S2Taps t;
   int ti, tk, knext;
@@ -382,15 +389,16 @@ struct ConvFilterS2MC {
 //    lane and stepped by (BK / Wo, BK % Wo) with a carry (no division).
 //  * otherwise (stride 2): image / row / column of each pixel are carried the same way and the address is rebuilt from
 //    them, relative to the image of pixel k0 (wave-uniform, stepped alongside).
-template <int TILE>
+template <int TILE, int NT = NTHREADS>
 struct ConvIm2colMC {
   static constexpr bool KC = false;
   static constexpr int LDT = TILE + 32;
   static constexpr int PLANE = BK * LDT;  // halfwords of one bf16 plane
-  static constexpr int NV = TILE / 32;
+  
   static constexpr int LD = TILE + 4;  // LDS row stride (floats)
   static constexpr int VPR = TILE / 4;
-  static constexpr int RPP = NTHREADS / VPR;
+  static constexpr int RPP = NT / VPR;
+  static constexpr int NV = BK / RPP;
   struct P { const float* x; ConvGeom g; int cols; int K; };
   const float* x; int c4, kr0, K, H, W, C, Ho, Wo, st, dh, dw, cc, bias; bool ok;
   bool linear, halo;

@@ -179,9 +179,7 @@ def linear_bwd_data(dy: torch.Tensor, w: torch.Tensor, aux=None, auxmode: int = 
 
 
 def _wgrad_splitk(n_out: int, n_in: int, rows: int) -> int:
-    tiles = ((n_out + 127) // 128) * ((n_in + 127) // 128)
-    want = max(1, (1536 + tiles - 1) // tiles)
-    return int(max(1, min(want, rows // 256, 512)))
+    return int(_lib.load().cxrk_gemm_wgrad_splitk(n_out, n_in, rows))
 
 
 def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
