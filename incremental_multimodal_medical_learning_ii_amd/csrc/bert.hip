@@ -105,14 +105,85 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     part[((long)blockIdx.x * 2 + 1) * H + c] = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
   }
 }
-__global__ void ln_bwd_final_kernel(const float* __restrict__ part, int nblk, int H, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= H) return;
-  float a = 0.f, b = 0.f;
-  for (int p = 0; p < nblk; ++p) { a += part[((long)p * 2) * H + c]; b += part[((long)p * 2 + 1) * H + c]; }
-  dgamma[c] = accumulate ? dgamma[c] + a : a;
-  dbeta[c] = accumulate ? dbeta[c] + b : b;
+// H % 4 == 0: a lane owns float4 columns (lane + 64*i)*4..+3 -> 16-byte loads / stores, a quarter of the instructions.
+constexpr int LN_MAXV4 = LN_MAXV / 4;
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                         long rows, int H, int rows_per, float* __restrict__ dx,
+                                                         const float* __restrict__ dx_add, float* __restrict__ part) {
+  __shared__ float sh[2][4][64 * LN_MAXV];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * rows_per;
+  const long r1 = min(rows, r0 + rows_per);
+  const int H4 = H / 4;
+  float4 dg[LN_MAXV4], db[LN_MAXV4], gm[LN_MAXV4];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV4; ++i) {
+    dg[i] = z4; db[i] = z4;
+    const int c4 = lane + i * 64;
+    gm[i] = c4 < H4 ? *reinterpret_cast<const float4*>(gamma + c4 * 4) : z4;
+  }
+  for (long row = r0 + w; row < r1; row += 4) {
+    float4 g[LN_MAXV4], xh[LN_MAXV4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV4; ++i) {
+      const int c4 = lane + i * 64;
+      float4 d = z4, x_ = z4;
+      if (c4 < H4) { d = *reinterpret_cast<const float4*>(dy + row * H + c4 * 4); x_ = *reinterpret_cast<const float4*>(xhat + row * H + c4 * 4); }
+      xh[i] = x_;
+      g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
+      dg[i].x += d.x * x_.x; dg[i].y += d.y * x_.y; dg[i].z += d.z * x_.z; dg[i].w += d.w * x_.w;
+      db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+      s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+      s2 += (g[i].x * x_.x + g[i].y * x_.y) + (g[i].z * x_.z + g[i].w * x_.w);
+    }
+    s1 = wave_sum(s1) / (float)H; s2 = wave_sum(s2) / (float)H;
+    const float rs = rstd[row];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV4; ++i) {
+      const int c4 = lane + i * 64;
+      if (c4 < H4) {
+        float4 o = make_float4(rs * (g[i].x - s1 - xh[i].x * s2), rs * (g[i].y - s1 - xh[i].y * s2),
+                               rs * (g[i].z - s1 - xh[i].z * s2), rs * (g[i].w - s1 - xh[i].w * s2));
+        if (dx_add) { const float4 a = *reinterpret_cast<const float4*>(dx_add + row * H + c4 * 4); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+        *reinterpret_cast<float4*>(dx + row * H + c4 * 4) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXV4; ++i) {
+    const int c = (lane + i * 64) * 4;
+    if (c < 64 * LN_MAXV) {
+      *reinterpret_cast<float4*>(&sh[0][w][c]) = dg[i];
+      *reinterpret_cast<float4*>(&sh[1][w][c]) = db[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    part[((long)blockIdx.x * 2 + 0) * H + c] = (sh[0][0][c] + sh[0][1][c]) + (sh[0][2][c] + sh[0][3][c]);
+    part[((long)blockIdx.x * 2 + 1) * H + c] = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
+  }
+}
+// Column sums of the block partials: 64 columns x 16 partial groups per block, groups added in order through LDS.
+__global__ __launch_bounds__(1024) void ln_bwd_final_kernel(const float* __restrict__ part, int nblk, int H, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int accumulate) {
+  __shared__ float sh[16][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, k = blockIdx.y;
+  float a = 0.f;
+  if (c < H)
+    for (int p = pl; p < nblk; p += 16) a += part[((long)p * 2 + k) * H + c];
+  sh[pl][cl] = a;
+  __syncthreads();
+  if (pl == 0 && c < H) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sh[i][cl];
+    float* out = k == 0 ? dgamma : dbeta;
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -123,11 +194,34 @@ __global__ void ln_bwd_final_kernel(const float* __restrict__ part, int nblk, in
 constexpr int AD = 64;       // max head dim
 constexpr int AL = 64;       // max sequence length handled here
 
+// Register tiling: a thread owns a 2x2 block of an L x L product (operands read as float4 along the head dimension:
+// 4 ds_read_b128 per 16 FMAs) or 2 rows x 4 columns of an L x dH product (2-3 LDS reads per 8 FMAs).  With one output
+// element per thread and two ds_read_b32 per FMA the kernels were bound by LDS bandwidth (0.22 ms / 0.46 ms per layer).
+__device__ __forceinline__ float dot4(const float4& a, const float4& b, float s) {
+  return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, fmaf(a.w, b.w, s))));
+}
+__device__ __forceinline__ void fma4(float4& acc, float p, const float4& v) {
+  acc.x = fmaf(p, v.x, acc.x); acc.y = fmaf(p, v.y, acc.y); acc.z = fmaf(p, v.z, acc.z); acc.w = fmaf(p, v.w, acc.w);
+}
+// Out[i][j] = sum_d X[i][d] * Y[j][d] for a 2x2 block (rows clamped to L-1; the caller discards the clamped duplicates)
+__device__ __forceinline__ void dot2x2(const float* X, const float* Y, int ALD, int d4n, int i0, int i1, int j0, int j1,
+                                       float (&o)[2][2]) {
+  o[0][0] = o[0][1] = o[1][0] = o[1][1] = 0.f;
+  const float4* x0 = reinterpret_cast<const float4*>(X + i0 * ALD); const float4* x1 = reinterpret_cast<const float4*>(X + i1 * ALD);
+  const float4* y0 = reinterpret_cast<const float4*>(Y + j0 * ALD); const float4* y1 = reinterpret_cast<const float4*>(Y + j1 * ALD);
+#pragma unroll 4
+  for (int d = 0; d < d4n; ++d) {
+    const float4 a0 = x0[d], a1 = x1[d], b0 = y0[d], b1 = y1[d];
+    o[0][0] = dot4(a0, b0, o[0][0]); o[0][1] = dot4(a0, b1, o[0][1]);
+    o[1][0] = dot4(a1, b0, o[1][0]); o[1][1] = dot4(a1, b1, o[1][1]);
+  }
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const long* __restrict__ mask, int L,
                                                        int nH, int dH, float scale, float* __restrict__ ctx,
                                                        float* __restrict__ probs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int ALD = dH + 1;
+  const int ALD = dH + 4;   // 16-byte aligned rows
   float* Qs = smem; float* Ks = Qs + L * ALD; float* Vs = Ks + L * ALD; float* Ps = Vs + L * ALD;  // Ps[L][L+1]
   const int b = blockIdx.x / nH, hd = blockIdx.x % nH;
   const int ld = 3 * nH * dH;
@@ -135,23 +229,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   const float* base = qkv + (long)b * L * ld + hd * dH;
   for (int i = threadIdx.x; i < L * d4; i += 256) {
     const int row = i / d4, c4 = i % d4;
-    const float4 q = *reinterpret_cast<const float4*>(base + (long)row * ld + c4 * 4);
-    const float4 k = *reinterpret_cast<const float4*>(base + (long)row * ld + nH * dH + c4 * 4);
-    const float4 v = *reinterpret_cast<const float4*>(base + (long)row * ld + 2 * nH * dH + c4 * 4);
-    float* qd = Qs + row * ALD + c4 * 4; qd[0] = q.x; qd[1] = q.y; qd[2] = q.z; qd[3] = q.w;
-    float* kd = Ks + row * ALD + c4 * 4; kd[0] = k.x; kd[1] = k.y; kd[2] = k.z; kd[3] = k.w;
-    float* vd = Vs + row * ALD + c4 * 4; vd[0] = v.x; vd[1] = v.y; vd[2] = v.z; vd[3] = v.w;
+    *reinterpret_cast<float4*>(Qs + row * ALD + c4 * 4) = *reinterpret_cast<const float4*>(base + (long)row * ld + c4 * 4);
+    *reinterpret_cast<float4*>(Ks + row * ALD + c4 * 4) = *reinterpret_cast<const float4*>(base + (long)row * ld + nH * dH + c4 * 4);
+    *reinterpret_cast<float4*>(Vs + row * ALD + c4 * 4) = *reinterpret_cast<const float4*>(base + (long)row * ld + 2 * nH * dH + c4 * 4);
   }
   __syncthreads();
   const int LP = L + 1;
-  for (int e = threadIdx.x; e < L * L; e += 256) {
-    const int i = e / L, j = e % L;
-    float s = 0.f;
-#pragma unroll 16
-    for (int d = 0; d < dH; ++d) s = fmaf(Qs[i * ALD + d], Ks[j * ALD + d], s);
-    s *= scale;
-    if (mask && mask[(long)b * L + j] == 0) s = -INFINITY;
-    Ps[i * LP + j] = s;
+  const int nb = (L + 1) / 2;
+  for (int blk = threadIdx.x; blk < nb * nb; blk += 256) {
+    const int i0 = 2 * (blk / nb), j0 = 2 * (blk % nb);
+    const int i1 = min(i0 + 1, L - 1), j1 = min(j0 + 1, L - 1);
+    float o[2][2];
+    dot2x2(Qs, Ks, ALD, d4, i0, i1, j0, j1, o);
+    const bool m0 = mask && mask[(long)b * L + j0] == 0, m1 = mask && mask[(long)b * L + j1] == 0;
+    Ps[i0 * LP + j0] = m0 ? -INFINITY : o[0][0] * scale;
+    Ps[i0 * LP + j1] = m1 ? -INFINITY : o[0][1] * scale;
+    Ps[i1 * LP + j0] = m0 ? -INFINITY : o[1][0] * scale;
+    Ps[i1 * LP + j1] = m1 ? -INFINITY : o[1][1] * scale;
   }
   __syncthreads();
   // softmax: 4 lanes per row
@@ -174,11 +268,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   }
   __syncthreads();
   float* out = ctx + (long)b * L * (nH * dH) + hd * dH;
-  for (int e = threadIdx.x; e < L * dH; e += 256) {
-    const int i = e / dH, d = e % dH;
-    float s = 0.f;
-    for (int j = 0; j < L; ++j) s = fmaf(Ps[i * LP + j], Vs[j * ALD + d], s);
-    out[(long)i * (nH * dH) + d] = s;
+  for (int blk = threadIdx.x; blk < nb * d4; blk += 256) {
+    const int i0 = 2 * (blk / d4), dq = blk % d4;
+    const int i1 = min(i0 + 1, L - 1);
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    for (int j = 0; j < L; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(Vs + j * ALD + dq * 4);
+      fma4(a0, Ps[i0 * LP + j], v); fma4(a1, Ps[i1 * LP + j], v);
+    }
+    *reinterpret_cast<float4*>(out + (long)i0 * (nH * dH) + dq * 4) = a0;
+    if (i0 + 1 < L) *reinterpret_cast<float4*>(out + (long)i1 * (nH * dH) + dq * 4) = a1;
   }
 }
 
@@ -187,7 +286,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ dctx, int L, int nH, int dH, float scale,
                                                        float* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int ALD = dH + 1;
+  const int ALD = dH + 4;
   float* Qs = smem; float* Ks = Qs + L * ALD; float* Vs = Ks + L * ALD; float* Os = Vs + L * ALD;
   float* Ps = Os + L * ALD; float* Ds = Ps + L * (L + 1);  // Ps = P, Ds = dS
   const int b = blockIdx.x / nH, hd = blockIdx.x % nH;
@@ -197,26 +296,23 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   const float* dob = dctx + (long)b * L * (nH * dH) + hd * dH;
   for (int i = threadIdx.x; i < L * d4; i += 256) {
     const int row = i / d4, c4 = i % d4;
-    const float4 q = *reinterpret_cast<const float4*>(base + (long)row * ld + c4 * 4);
-    const float4 k = *reinterpret_cast<const float4*>(base + (long)row * ld + nH * dH + c4 * 4);
-    const float4 v = *reinterpret_cast<const float4*>(base + (long)row * ld + 2 * nH * dH + c4 * 4);
-    const float4 o = *reinterpret_cast<const float4*>(dob + (long)row * (nH * dH) + c4 * 4);
-    float* qd = Qs + row * ALD + c4 * 4; qd[0] = q.x; qd[1] = q.y; qd[2] = q.z; qd[3] = q.w;
-    float* kd = Ks + row * ALD + c4 * 4; kd[0] = k.x; kd[1] = k.y; kd[2] = k.z; kd[3] = k.w;
-    float* vd = Vs + row * ALD + c4 * 4; vd[0] = v.x; vd[1] = v.y; vd[2] = v.z; vd[3] = v.w;
-    float* od = Os + row * ALD + c4 * 4; od[0] = o.x; od[1] = o.y; od[2] = o.z; od[3] = o.w;
+    *reinterpret_cast<float4*>(Qs + row * ALD + c4 * 4) = *reinterpret_cast<const float4*>(base + (long)row * ld + c4 * 4);
+    *reinterpret_cast<float4*>(Ks + row * ALD + c4 * 4) = *reinterpret_cast<const float4*>(base + (long)row * ld + nH * dH + c4 * 4);
+    *reinterpret_cast<float4*>(Vs + row * ALD + c4 * 4) = *reinterpret_cast<const float4*>(base + (long)row * ld + 2 * nH * dH + c4 * 4);
+    *reinterpret_cast<float4*>(Os + row * ALD + c4 * 4) = *reinterpret_cast<const float4*>(dob + (long)row * (nH * dH) + c4 * 4);
   }
   const int LP = L + 1;
   const float* pb = probs + ((long)b * nH + hd) * L * L;
   for (int e = threadIdx.x; e < L * L; e += 256) Ps[(e / L) * LP + (e % L)] = pb[e];
   __syncthreads();
   // dP -> Ds
-  for (int e = threadIdx.x; e < L * L; e += 256) {
-    const int i = e / L, j = e % L;
-    float s = 0.f;
-#pragma unroll 16
-    for (int d = 0; d < dH; ++d) s = fmaf(Os[i * ALD + d], Vs[j * ALD + d], s);
-    Ds[i * LP + j] = s;
+  const int nb = (L + 1) / 2;
+  for (int blk = threadIdx.x; blk < nb * nb; blk += 256) {
+    const int i0 = 2 * (blk / nb), j0 = 2 * (blk % nb);
+    const int i1 = min(i0 + 1, L - 1), j1 = min(j0 + 1, L - 1);
+    float o[2][2];
+    dot2x2(Os, Vs, ALD, d4, i0, i1, j0, j1, o);
+    Ds[i0 * LP + j0] = o[0][0]; Ds[i0 * LP + j1] = o[0][1]; Ds[i1 * LP + j0] = o[1][0]; Ds[i1 * LP + j1] = o[1][1];
   }
   __syncthreads();
   {
@@ -230,17 +326,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   }
   __syncthreads();
   float* dq = dqkv + (long)b * L * ld + hd * dH;
-  for (int e = threadIdx.x; e < L * dH; e += 256) {
-    const int i = e / dH, d = e % dH;
-    float sq = 0.f, sk = 0.f, sv = 0.f;
+  for (int blk = threadIdx.x; blk < nb * d4; blk += 256) {
+    const int i0 = 2 * (blk / d4), c = blk % d4;
+    const int i1 = min(i0 + 1, L - 1);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 q0 = z, q1 = z, k0 = z, k1 = z, v0 = z, v1 = z;
     for (int j = 0; j < L; ++j) {
-      sq = fmaf(Ds[i * LP + j], Ks[j * ALD + d], sq);   // dQ[i] = sum_j dS[i][j] K[j]
-      sk = fmaf(Ds[j * LP + i], Qs[j * ALD + d], sk);   // dK[i] = sum_j dS[j][i] Q[j]
-      sv = fmaf(Ps[j * LP + i], Os[j * ALD + d], sv);   // dV[i] = sum_j P[j][i] dO[j]
+      const float4 kj = *reinterpret_cast<const float4*>(Ks + j * ALD + c * 4);
+      const float4 qj = *reinterpret_cast<const float4*>(Qs + j * ALD + c * 4);
+      const float4 oj = *reinterpret_cast<const float4*>(Os + j * ALD + c * 4);
+      fma4(q0, Ds[i0 * LP + j], kj); fma4(q1, Ds[i1 * LP + j], kj);   // dQ[i] = sum_j dS[i][j] K[j]
+      fma4(k0, Ds[j * LP + i0], qj); fma4(k1, Ds[j * LP + i1], qj);   // dK[i] = sum_j dS[j][i] Q[j]
+      fma4(v0, Ps[j * LP + i0], oj); fma4(v1, Ps[j * LP + i1], oj);   // dV[i] = sum_j P[j][i] dO[j]
     }
-    dq[(long)i * ld + d] = sq;
-    dq[(long)i * ld + nH * dH + d] = sk;
-    dq[(long)i * ld + 2 * nH * dH + d] = sv;
+    float* r0 = dq + (long)i0 * ld + c * 4;
+    *reinterpret_cast<float4*>(r0) = q0; *reinterpret_cast<float4*>(r0 + nH * dH) = k0; *reinterpret_cast<float4*>(r0 + 2 * nH * dH) = v0;
+    if (i0 + 1 < L) {
+      float* r1 = dq + (long)i1 * ld + c * 4;
+      *reinterpret_cast<float4*>(r1) = q1; *reinterpret_cast<float4*>(r1 + nH * dH) = k1; *reinterpret_cast<float4*>(r1 + 2 * nH * dH) = v1;
+    }
   }
 }
 
@@ -287,8 +391,8 @@ extern "C" int cxrk_residual_ln_fwd(const float* x, const float* res, const floa
 }
 
 static int ln_bwd_blocks(long rows) {
-  long nb = (rows + 63) / 64;
-  if (nb > 256) nb = 256;   // one block per CU; the final reduction walks nb partials per column
+  long nb = (rows + 15) / 16;
+  if (nb > 2048) nb = 2048;   // 8 blocks per CU keep enough rows in flight; the final reduction sums the partials in 16 groups
   if (nb < 1) nb = 1;
   return (int)nb;
 }
@@ -302,23 +406,27 @@ extern "C" int cxrk_residual_ln_bwd(const float* dy, const float* xhat, const fl
   if (ws == nullptr || ws_bytes < (size_t)nb * 2 * H * sizeof(float)) return CXRK_ERR_WS;
   const int rows_per = (int)((rows + nb - 1) / nb);
   nb = (int)((rows + rows_per - 1) / rows_per);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, stream, dy, xhat, rstd, gamma, rows, H, rows_per, dx, dx_add, ws);
+  const bool vec = (H % 4 == 0) && aligned16(dy) && aligned16(xhat) && aligned16(gamma) && aligned16(dx) && (!dx_add || aligned16(dx_add));
+  if (vec)
+    hipLaunchKernelGGL(ln_bwd_vec_kernel, dim3(nb), dim3(256), 0, stream, dy, xhat, rstd, gamma, rows, H, rows_per, dx, dx_add, ws);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, stream, dy, xhat, rstd, gamma, rows, H, rows_per, dx, dx_add, ws);
   CXRK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(ceil_div(H, 256)), dim3(256), 0, stream, ws, nb, H, dgamma, dbeta, accumulate);
+  hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(ceil_div(H, 64), 2), dim3(1024), 0, stream, ws, nb, H, dgamma, dbeta, accumulate);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
 }
 
 extern "C" int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, int nH, int dH, float* ctx, float* probs,
                              hipStream_t stream) {
-  CXRK_CHECK_ARG(qkv && ctx && B > 0 && nH > 0 && aligned16(qkv));
+  CXRK_CHECK_ARG(qkv && ctx && B > 0 && nH > 0 && aligned16(qkv) && aligned16(ctx));
   if (dH > AD || dH < 4 || (dH % 4) != 0 || L > AL || L < 1) return CXRK_ERR_UNSUPPORTED;
-  const int ALD = dH + 1;
+  const int ALD = dH + 4;
   const size_t sh = (size_t)(3 * L * ALD + L * (L + 1)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)((3 * AL * (AD + 1) + AL * (AL + 1)) * sizeof(float)));
+                        (int)((3 * AL * (AD + 4) + AL * (AL + 1)) * sizeof(float)));
     attr_set = true;
   }
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * nH)), dim3(256), sh, stream, qkv, mask, L, nH, dH,
@@ -329,14 +437,14 @@ extern "C" int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, i
 
 extern "C" int cxrk_attn_bwd(const float* qkv, const float* probs, const float* dctx, int B, int L, int nH, int dH,
                              float* dqkv, hipStream_t stream) {
-  CXRK_CHECK_ARG(qkv && probs && dctx && dqkv && B > 0 && nH > 0 && aligned16(qkv) && aligned16(dctx));
+  CXRK_CHECK_ARG(qkv && probs && dctx && dqkv && B > 0 && nH > 0 && aligned16(qkv) && aligned16(dctx) && aligned16(dqkv));
   if (dH > AD || dH < 4 || (dH % 4) != 0 || L > AL || L < 1) return CXRK_ERR_UNSUPPORTED;
-  const int ALD = dH + 1;
+  const int ALD = dH + 4;
   const size_t sh = (size_t)(4 * L * ALD + 2 * L * (L + 1)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)((4 * AL * (AD + 1) + 2 * AL * (AL + 1)) * sizeof(float)));
+                        (int)((4 * AL * (AD + 4) + 2 * AL * (AL + 1)) * sizeof(float)));
     attr_set = true;
   }
   hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * nH)), dim3(256), sh, stream, qkv, probs, dctx, L, nH, dH,
