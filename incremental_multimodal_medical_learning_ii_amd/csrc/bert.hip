@@ -392,7 +392,7 @@ extern "C" int cxrk_residual_ln_fwd(const float* x, const float* res, const floa
 
 static int ln_bwd_blocks(long rows) {
   long nb = (rows + 15) / 16;
-  if (nb > 2048) nb = 2048;   // 8 blocks per CU keep enough rows in flight; the final reduction sums the partials in 16 groups
+  if (nb > 1024) nb = 1024;   // 4 blocks per CU keep enough rows in flight; the final reduction sums the partials in 16 groups
   if (nb < 1) nb = 1;
   return (int)nb;
 }
