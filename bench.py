@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+PEAK_HBM_GBS = 8000.0           # same guide, "HBM3E 8 TB/s peak" (about 6.3 TB/s achievable)
 FLOP_PER_PAIR_STEP = 41.1e9     # 3 x (8.2 GFLOP ResNet-50+projector + 5.5 GFLOP CXR-BERT, L=32, no MLM head); SURVEY.md §8d
 
 
@@ -234,28 +235,44 @@ def main():
             if summ:
                 for k_, v_ in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                     log(f"  {k_:58s} {v_['launches'] / args.steps:6.1f} launches/step {v_['ms'] / args.steps:8.2f} ms/step "
-                        f"{v_['flops'] / (v_['ms'] * 1e-3) / 1e12:6.1f} TFLOP/s")
+                        f"{v_['flops'] / (v_['ms'] * 1e-3) / 1e12:6.1f} TFLOP/s {v_['bytes'] / (v_['ms'] * 1e-3) / 1e9:7.0f} GB/s (algorithmic)")
                 key, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
-                achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-                peak = PEAK_BF16_MFMA_TFLOPS if key.startswith("gemm_x3") else PEAK_FP32_MFMA_TFLOPS
+                secs = d["ms"] * 1e-3
+                tflops = d["flops"] / secs / 1e12
+                gbps = d["bytes"] / secs / 1e9
+                peak_fl = PEAK_BF16_MFMA_TFLOPS if key.startswith("gemm_x3") else PEAK_FP32_MFMA_TFLOPS
+                # price the dominant kernel against BOTH roofs and report the one it sits closer to (the binding one)
+                frac_mfma, frac_hbm = tflops / peak_fl, gbps / PEAK_HBM_GBS
                 tot_ms = sum(v["ms"] for v in summ.values())
                 tot_fl = sum(v["flops"] for v in summ.values())
+                tot_by = sum(v["bytes"] for v in summ.values())
                 traffic = None
-                try:  # HBM bytes per launch of this kernel from the committed PMC pass of the same command
+                try:  # HBM bytes per launch of this kernel from the committed PMC passes (scripts/pmc_traffic.sh)
                     pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                    traffic = pmc["kernels"].get(key.replace("gemm_f32_kernel<", "gemm_f32_kernel<").replace(",2,2>", ",2,2>"), {}).get("hbm_bytes_per_launch")
+                    traffic = pmc["kernels"].get(key, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-                out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                                   "frac": achieved / peak, "traffic": traffic, "kernel": key,
-                                   "note": ("algorithmic 2*M*N*K FLOPs; the split-bf16 mainloop executes 3 bf16 MFMAs per product, "
-                                            "i.e. 3x this rate on the matrix pipe, priced against the dense bf16 peak")
-                                           if key.startswith("gemm_x3") else "exact fp32 MFMA, priced against the fp32 matrix peak",
+                mfma_note = ("algorithmic 2*M*N*K FLOPs; the split-bf16 mainloop executes 3 bf16 MFMAs per product (3x this rate on "
+                             "the matrix pipe), priced against the dense bf16 peak") if key.startswith("gemm_x3") else \
+                            "exact fp32 MFMA, priced against the fp32 matrix peak"
+                hbm = frac_hbm >= frac_mfma
+                out["roofline"] = {"bound": "hbm" if hbm else "mfma",
+                                   "achieved": gbps if hbm else tflops, "peak": PEAK_HBM_GBS if hbm else peak_fl,
+                                   "unit": "GB/s" if hbm else "TFLOP/s", "frac": frac_hbm if hbm else frac_mfma,
+                                   "traffic": traffic, "kernel": key,
+                                   "note": ("algorithmic bytes: every operand and fused side input (ReLU source, residual, BatchNorm "
+                                            "terms) read once + the output written once, fp32; summed over the launches of this "
+                                            "instantiation / their HIP-event time") if hbm else mfma_note,
                                    "launches_per_step": d["launches"] / args.steps,
                                    "avg_launch_ms": d["ms"] / d["launches"],
                                    "gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+                                   "algorithmic_mb_per_launch": d["bytes"] / d["launches"] / 1e6,
+                                   "other_bound": {"bound": "mfma" if hbm else "hbm", "achieved": tflops if hbm else gbps,
+                                                   "peak": peak_fl if hbm else PEAK_HBM_GBS, "unit": "TFLOP/s" if hbm else "GB/s",
+                                                   "frac": frac_mfma if hbm else frac_hbm, "note": mfma_note if hbm else ""},
                                    "family": {"kernel": "gemm_*_kernel<*> (all MFMA mainloop instantiations)",
-                                              "achieved": tot_fl / (tot_ms * 1e-3) / 1e12,
+                                              "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
+                                              "algorithmic_gbps": tot_by / (tot_ms * 1e-3) / 1e9,
                                               "share_of_step_time": tot_ms / (dt * 1e3)}}
         if secondary is not None:
             out["other_precision"] = secondary

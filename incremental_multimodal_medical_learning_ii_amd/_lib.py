@@ -62,6 +62,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_weight_reset_ws_bytes": (Z, []),
     "cxrk_weight_reset": (I, [P, P, L, F, P, P, Z, P]),
     "cxrk_gemm_wgrad_splitk": (I, [I, I, I]),
+    "cxrk_gemm_wide_tile": (I, [I, I, L, I, I]),
     "cxrk_set_precision": (I, [I]),
     "cxrk_get_precision": (I, []),
     "cxrk_version": (c_char_p, []),

@@ -99,6 +99,14 @@ extern "C" int cxrk_gemm_wgrad_splitk(int M, int N, int K) {
   return (int)sk;
 }
 
+// 1 when a launch of this shape takes the 256x256 tile in the current precision mode.  kind: 0 = plain epilogue (dense
+// weight gradient / split-K / convolution weight gradient), 1 = convolution forward, 2 = convolution data gradient,
+// 3 = dense layer with a fused epilogue.  (Reporting only: lets the host label its launch timings by mainloop.)
+extern "C" int cxrk_gemm_wide_tile(int M, int N, long K, int splitk, int kind) {
+  if (kind == 3) return wide_mode() == 2 && use_wide256(M, N, K, splitk);
+  return use_wide256(M, N, K, splitk, false, kind == 1 ? WIDE_MINK_FPROP : (kind == 2 ? WIDE_MINK_DGRAD : WIDE_MINK_PLAIN));
+}
+
 extern "C" size_t cxrk_gemm_splitk_ws_bytes(int M, int N, int splitk) {
   return splitk > 1 ? (size_t)splitk * (size_t)M * (size_t)N * sizeof(float) : 0;
 }

@@ -46,11 +46,12 @@ def _rowmajor2d(t: torch.Tensor, name: str) -> Tuple[torch.Tensor, int]:
 class LaunchProfiler:
     """Optional per-launch timing of the MFMA GEMM family with HIP events recorded on the launch stream
     (bench.py's `roofline` object).  Off by default; when on, every GEMM / implicit-GEMM launch is bracketed by two
-    events and tagged with its kernel instantiation and algorithmic FLOPs (2*M*N*K)."""
+    events and tagged with its kernel instantiation, its algorithmic FLOPs (2*M*N*K) and its algorithmic HBM bytes (every
+    operand and side input read once, every output written once)."""
 
     def __init__(self):
         self.on = False
-        self.rows = []  # (key, flops, start_event, end_event)
+        self.rows = []  # (key, flops, bytes, start_event, end_event)
 
     def start(self):
         self.on, self.rows = True, []
@@ -58,21 +59,22 @@ class LaunchProfiler:
     def stop(self):
         self.on = False
 
-    def bracket(self, key: str, flops: float):
+    def bracket(self, key: str, flops: float, nbytes: float = 0.0):
         if not self.on:
             return None
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        self.rows.append((key, flops, a, b))
+        self.rows.append((key, flops, nbytes, a, b))
         return b
 
     def summary(self):
-        """{kernel: {"launches", "flops", "ms"}} — call after torch.cuda.synchronize()."""
+        """{kernel: {"launches", "flops", "bytes", "ms"}} — call after torch.cuda.synchronize()."""
         out = {}
-        for key, flops, a, b in self.rows:
-            d = out.setdefault(key, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        for key, flops, nbytes, a, b in self.rows:
+            d = out.setdefault(key, {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["flops"] += flops
+            d["bytes"] += nbytes
             d["ms"] += a.elapsed_time(b)
         return out
 
@@ -88,6 +90,13 @@ def _kern(flops: float, exact: bool = False) -> str:
     """Name of the mainloop a launch runs (mirrors launch_gemm's policy in csrc/gemm_core.h)."""
     split = _lib.get_precision() == "split_bf16" and not exact and flops >= 1073741824.0
     return "gemm_x3_kernel" if split else "gemm_f32_kernel"
+
+
+def _label(la: str, lb: str, tile: str, M: int, N: int, K: int, splitk: int, kind: int, exact: bool = False) -> str:
+    """Profiler key of a launch: mainloop<A loader,B loader,tile>; the 256x256 kernel when the library would pick it."""
+    if not exact and _lib.load().cxrk_gemm_wide_tile(M, N, K, splitk, kind):
+        return f"gemm_x3w_kernel<{la},{lb}>"
+    return f"{_kern(2.0 * M * N * K, exact)}<{la},{lb},{tile}>"
 
 
 class _Workspace:
@@ -145,8 +154,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K:
         wsb = lib.cxrk_gemm_splitk_ws_bytes(M, N, splitk)
         ws = workspace(wsb, out.device)
         wsb = ws.numel() * 4
-    ev = profiler.bracket(f"{_kern(2.0 * M * N * K)}<Dense{'MC' if trans_a else 'KC'},Dense{'KC' if trans_b else 'MC'},{_tile(M, N)}>",
-                          2.0 * M * N * K) if profiler.on else None
+    plain = bias is None and residual is None and aux is None and preact_out is None and act == 0
+    ev = profiler.bracket(_label(f"Dense{'MC' if trans_a else 'KC'}", f"Dense{'KC' if trans_b else 'MC'}", _tile(M, N), M, N, K, splitk,
+                                 0 if (plain or splitk > 1) else 3), 2.0 * M * N * K,
+                          4.0 * (M * K + N * K + M * N * (1 + (residual is not None) + (aux is not None) + (preact_out is not None)
+                                                       + int(bool(accumulate))))) if profiler.on else None
     rc = lib.cxrk_gemm_f32(int(trans_a), int(trans_b), M, N, K, _p(a), lda, _p(b), ldb, _p(out), ldc, _p(bias),
                            _p(residual), ldr, _p(aux), ldaux, auxmode, _p(preact_out), ldc2, act, float(alpha),
                            int(accumulate), int(splitk), _p(ws), wsb, _stream())
@@ -222,7 +234,9 @@ def conv_fwd(x, w_scaled, shift, residual, y, N, H, W, C, Ko, R, S, stride, pad,
     if profiler.on:
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         fl = 2.0 * N * Ho * Wo * Ko * R * S * C
-        ev = profiler.bracket(f"{_kern(fl)}<ConvIm2colKC,DenseKC,{'4,1' if Ko <= 64 else '2,2'}>", fl)
+        ev = profiler.bracket(_label("ConvIm2colKC", "DenseKC", "4,1" if Ko <= 64 else "2,2", N * Ho * Wo, Ko, R * S * C, 1,
+                                     1 if C % 32 == 0 else 3), fl,
+                              4.0 * (N * H * W * C + Ko * R * S * C + N * Ho * Wo * Ko * (1 + (residual is not None))))
     rc = lib.cxrk_conv_bn_act_fwd(_p(_chk(x, "conv.x")), _p(w_scaled), _p(shift), _p(residual), _p(y), N, H, W, C, Ko,
                                   R, S, stride, pad, int(relu), _stream())
     if ev is not None:
@@ -237,7 +251,9 @@ def conv_bwd_data(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R, S, st
     if profiler.on:  # algorithmic FLOPs of a data gradient = those of the forward conv (stride-2 zero taps are waste)
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         fl = 2.0 * N * Ho * Wo * Ko * R * S * C
-        ev = profiler.bracket(f"{_kern(fl)}<ConvDgradKC,ConvFilterMC,{'4,1' if C <= 64 else '2,2'}>", fl)
+        ev = profiler.bracket(_label("ConvDgradKC", "ConvFilterMC", "4,1" if C <= 64 else "2,2", N * H * W, C, R * S * Ko, 1,
+                                     2 if stride == 1 else 3), fl,
+                              4.0 * (N * Ho * Wo * Ko + Ko * R * S * C + N * H * W * C * (1 + (residual is not None) + (relu_src is not None))))
     rc = lib.cxrk_conv_bn_act_bwd_data(_p(_chk(dy, "conv.dy")), _p(w_scaled), _p(residual), _p(relu_src), _p(dx), N, H,
                                        W, C, Ko, R, S, stride, pad, _stream())
     if ev is not None:
@@ -264,7 +280,9 @@ def conv_bwd_data_bnsum(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R,
     if profiler.on:
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         fl = 2.0 * N * Ho * Wo * Ko * R * S * C
-        ev = profiler.bracket(f"{_kern(fl)}<ConvDgradKC,ConvFilterMC,{'4,1' if C <= 64 else '2,2'}>", fl)
+        ev = profiler.bracket(_label("ConvDgradKC", "ConvFilterMC", "4,1" if C <= 64 else "2,2", N * H * W, C, R * S * Ko, 1,
+                                     2 if stride == 1 else 3), fl,
+                              4.0 * (N * Ho * Wo * Ko + Ko * R * S * C + N * H * W * C * (2 + (residual is not None) + (bn_sub is not None))))
     rc = lib.cxrk_conv_bn_act_bwd_data_bnsum(_p(_chk(dy, "conv.dy")), _p(w_scaled), _p(residual), _p(relu_src), _p(dx), N, H, W, C,
                                              Ko, R, S, stride, pad, _p(bn_sub), _p(bn_beta), _p(bn_beta2), _p(sums), _p(ws),
                                              ws.numel() * 4, _stream())
@@ -283,7 +301,9 @@ def conv_bwd_params(x, dy, w, scale, rstd, rmean, sumdy, gamma, sumdyy, dw, dgam
     if profiler.on:
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         fl = 2.0 * N * Ho * Wo * Ko * R * S * Cpad
-        ev = profiler.bracket(f"{_kern(fl, Cpad <= 4)}<DenseMC,ConvIm2colMC,{'1,4' if Ko <= 64 else '2,2'}>", fl)
+        sk = lib.cxrk_gemm_wgrad_splitk(Ko, R * S * Cpad, N * Ho * Wo)
+        ev = profiler.bracket(_label("DenseMC", "ConvIm2colMC", "1,4" if Ko <= 64 else "2,2", Ko, R * S * Cpad, N * Ho * Wo, sk, 0,
+                                     Cpad <= 4), fl, 4.0 * (N * H * W * Cpad + N * Ho * Wo * Ko + Ko * R * S * Cpad))
     check(lib.cxrk_conv_bn_act_bwd_params(_p(_chk(x, "conv.x")), _p(_chk(dy, "conv.dy")), _p(w), _p(scale), _p(rstd),
                                           _p(rmean), _p(sumdy), _p(gamma), _p(sumdyy), _p(dw), _p(dgamma), _p(dbeta),
                                           int(accumulate), N, H, W,
