@@ -156,59 +156,77 @@ __device__ __forceinline__ void gemm_epilogue64(f32x16 (&acc)[2][2], const EpiPa
 #pragma unroll
       for (int e = 0; e < 16; ++e) st[((e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[i][j][e];
     __builtin_amdgcn_wave_barrier();  // LDS serves one wave's accesses in issue order; keep the compiler from reordering
+    // Side inputs first, four rows at a time: the stores to C may alias them as far as the compiler knows, so left in
+    // program order every load would wait behind the previous row's store (one HBM round trip per row).
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int rl = t * 4 + rq;
-      const int grow = row0 + i * 32 + rl;
-      float4 v4 = *reinterpret_cast<const float4*>(st + rl * 64 + c4 * 4);
-      if (grow >= M || col >= N) continue;
-      long row = grow;
-      if (ep.rm_on) {
-        const int b_ = grow % ep.rm_Ws; const int q_ = grow / ep.rm_Ws; const int a_ = q_ % ep.rm_Hs; const int n_ = q_ / ep.rm_Hs;
-        row = ((long)n_ * ep.rm_H + 2 * a_ + ep.rm_ph) * ep.rm_W + 2 * b_ + ep.rm_pw;
-      }
-      float v[4] = {ep.alpha * v4.x + bv.x, ep.alpha * v4.y + bv.y, ep.alpha * v4.z + bv.z, ep.alpha * v4.w + bv.w};
-      if ((CXRK_ABL == 5 || CXRK_ABL == 6) && v[0] != 12345.678f) continue;  // ablation: drop the epilogue traffic
-      if (ep.vec) {
-        if (ep.R) { const float4 q = *reinterpret_cast<const float4*>(ep.R + row * ep.ldr + col); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
-        if (ep.C2) *reinterpret_cast<float4*>(ep.C2 + row * ep.ldc2 + col) = make_float4(v[0], v[1], v[2], v[3]);
-        if (ep.act == 1) {
+    for (int tg = 0; tg < 2; ++tg) {
+      long rows[4]; bool live[4];
+      float4 pr[4], pa[4], ps[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-        } else if (ep.act == 2) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+      for (int u = 0; u < 4; ++u) {
+        const int rl = (tg * 4 + u) * 4 + rq;
+        const int grow = row0 + i * 32 + rl;
+        live[u] = grow < M && col < N;
+        long row = grow;
+        if (ep.rm_on) {
+          const int b_ = grow % ep.rm_Ws; const int q_ = grow / ep.rm_Ws; const int a_ = q_ % ep.rm_Hs; const int n_ = q_ / ep.rm_Hs;
+          row = ((long)n_ * ep.rm_H + 2 * a_ + ep.rm_ph) * ep.rm_W + 2 * b_ + ep.rm_pw;
         }
-        if (ep.auxmode) {
-          const float4 q4 = *reinterpret_cast<const float4*>(ep.aux + row * ep.ldaux + col);
-          const float ax[4] = {q4.x, q4.y, q4.z, q4.w};
+        rows[u] = row;
+        pr[u] = pa[u] = ps[u] = zero4();
+        if (ep.vec && live[u]) {
+          if (ep.R) pr[u] = *reinterpret_cast<const float4*>(ep.R + row * ep.ldr + col);
+          if (ep.auxmode) pa[u] = *reinterpret_cast<const float4*>(ep.aux + row * ep.ldaux + col);
+          if (ep.bn_part && ep.bn_sub) ps[u] = *reinterpret_cast<const float4*>(ep.bn_sub + row * ep.bn_ldsub + col);
+        }
+      }
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = ep.auxmode == 1 ? (ax[q] > 0.f ? v[q] : 0.f) : v[q] * gelu_erf_grad(ax[q]);
-          if (ep.bn_part) {
-            float sb[4] = {0.f, 0.f, 0.f, 0.f};
-            if (ep.bn_sub) { const float4 s4 = *reinterpret_cast<const float4*>(ep.bn_sub + row * ep.bn_ldsub + col); sb[0] = s4.x; sb[1] = s4.y; sb[2] = s4.z; sb[3] = s4.w; }
+      for (int u = 0; u < 4; ++u) {
+        const int rl = (tg * 4 + u) * 4 + rq;
+        const float4 v4 = *reinterpret_cast<const float4*>(st + rl * 64 + c4 * 4);
+        if (!live[u]) continue;
+        const long row = rows[u];
+        float v[4] = {ep.alpha * v4.x + bv.x, ep.alpha * v4.y + bv.y, ep.alpha * v4.z + bv.z, ep.alpha * v4.w + bv.w};
+        if ((CXRK_ABL == 5 || CXRK_ABL == 6) && v[0] != 12345.678f) continue;  // ablation: drop the epilogue traffic
+        if (ep.vec) {
+          if (ep.R) { v[0] += pr[u].x; v[1] += pr[u].y; v[2] += pr[u].z; v[3] += pr[u].w; }
+          if (ep.C2) *reinterpret_cast<float4*>(ep.C2 + row * ep.ldc2 + col) = make_float4(v[0], v[1], v[2], v[3]);
+          if (ep.act == 1) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              bs[0][q] += v[q];
-              bs[1][q] += v[q] * (ax[q] - sb[q] - bb1[q]);
-              bs[2][q] += v[q] * (sb[q] - bb2[q]);
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+          } else if (ep.act == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+          }
+          if (ep.auxmode) {
+            const float ax[4] = {pa[u].x, pa[u].y, pa[u].z, pa[u].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = ep.auxmode == 1 ? (ax[q] > 0.f ? v[q] : 0.f) : v[q] * gelu_erf_grad(ax[q]);
+            if (ep.bn_part) {
+              const float sb[4] = {ps[u].x, ps[u].y, ps[u].z, ps[u].w};
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                bs[0][q] += v[q];
+                bs[1][q] += v[q] * (ax[q] - sb[q] - bb1[q]);
+                bs[2][q] += v[q] * (sb[q] - bb2[q]);
+              }
             }
           }
-        }
-        if (ep.nt) { const f32x4 o = {v[0], v[1], v[2], v[3]}; __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(C + row * ep.ldc + col)); }
-        else *reinterpret_cast<float4*>(C + row * ep.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
+          if (ep.nt) { const f32x4 o = {v[0], v[1], v[2], v[3]}; __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(C + row * ep.ldc + col)); }
+          else *reinterpret_cast<float4*>(C + row * ep.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (col + q >= N) break;
-          float x = v[q];
-          if (ep.R) x += ep.R[row * ep.ldr + col + q];
-          if (ep.C2) ep.C2[row * ep.ldc2 + col + q] = x;
-          if (ep.act == 1) x = fmaxf(x, 0.f);
-          else if (ep.act == 2) x = gelu_erf(x);
-          if (ep.auxmode == 1) x = ep.aux[row * ep.ldaux + col + q] > 0.f ? x : 0.f;
-          else if (ep.auxmode == 2) x *= gelu_erf_grad(ep.aux[row * ep.ldaux + col + q]);
-          C[row * ep.ldc + col + q] = x;
+          for (int q = 0; q < 4; ++q) {
+            if (col + q >= N) break;
+            float x = v[q];
+            if (ep.R) x += ep.R[row * ep.ldr + col + q];
+            if (ep.C2) ep.C2[row * ep.ldc2 + col + q] = x;
+            if (ep.act == 1) x = fmaxf(x, 0.f);
+            else if (ep.act == 2) x = gelu_erf(x);
+            if (ep.auxmode == 1) x = ep.aux[row * ep.ldaux + col + q] > 0.f ? x : 0.f;
+            else if (ep.auxmode == 2) x *= gelu_erf_grad(ep.aux[row * ep.ldaux + col + q]);
+            C[row * ep.ldc + col + q] = x;
+          }
         }
       }
     }
@@ -563,7 +581,7 @@ static inline int stream_output(int M, int N, int splitk) { return (double)M * N
 // 256x256-tile policy.  CXRK_WIDE (environment, read once): 0 = never, 1 (default) = where it pays, 2 = wherever the
 // precision mode allows it (test coverage on small shapes).  "Pays": split-bf16 launch, both tile dimensions filled, a K
 // loop long enough to amortise the exposed prologue / epilogue of a one-block-per-CU kernel, and a tile count that fills
-// the 256 CUs in whole rounds to at least 70 %.
+// the 256 CUs in whole rounds to at least 80 %.
 inline int wide_mode() { static const int m = [] { const char* e = getenv("CXRK_WIDE"); return e ? atoi(e) : 1; }(); return m; }
 // min_k: shortest K loop (per split-K slab) for which the caller's kind of launch gains (measured per kind on the step's
 // shapes, scripts/layer_table.py: the heavier the fused epilogue, the longer the loop has to be to pay for exposing it).
@@ -579,7 +597,7 @@ static inline bool use_wide256(int M, int N, long K, int splitk, bool force_fp32
   if (kper < min_k) return false;
   const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256) * (splitk > 1 ? splitk : 1);
   const long rounds = (tiles + 255) / 256;
-  return tiles * 10 >= rounds * 256 * 7;
+  return tiles * 10 >= rounds * 256 * 8;
 }
 
 template <class LA, class LB>
