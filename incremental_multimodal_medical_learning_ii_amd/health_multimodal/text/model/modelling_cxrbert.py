@@ -85,7 +85,7 @@ class CXRBertModel(BertForMaskedLM):
             TE.fuse_qkv_(att.query.bias, att.key.bias, att.value.bias)
         return self
 
-    def _encode(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]):
+    def _encode(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], cls_only: bool = False):
         if not input_ids.is_cuda:
             raise RuntimeError("CXRBertModel runs on the MI355X only: move the model and inputs to 'cuda' "
                                "(there is no CPU fallback; the CPU oracle lives in oracle/ and is test-only)")
@@ -94,7 +94,7 @@ class CXRBertModel(BertForMaskedLM):
         if getattr(cfg, "hidden_act", "gelu") != "gelu":
             raise NotImplementedError(f"hidden_act={cfg.hidden_act!r}: only erf-GELU (CXR-BERT) is implemented")
         return TE.encode(self._hot_params(), input_ids, attention_mask, cfg.num_hidden_layers,
-                         cfg.num_attention_heads, cfg.layer_norm_eps)
+                         cfg.num_attention_heads, cfg.layer_norm_eps, cls_only)
 
     @torch.no_grad()
     def _mlm_logits(self, last_hidden: torch.Tensor) -> torch.Tensor:
@@ -146,11 +146,9 @@ class CXRBertModel(BertForMaskedLM):
                                       normalize_embeddings: bool = True) -> torch.Tensor:
         """Projected CLS embeddings [batch, projection_size], optionally L2-normalised
         (reference `modelling_cxrbert.py:117-141`)."""
-        outputs = self.forward(input_ids=input_ids, attention_mask=attention_mask,
-                               output_cls_projected_embedding=True, return_dict=True, output_mlm_logits=False)
-        assert isinstance(outputs, CXRBertOutput)
-        cls_projected_embedding = outputs.cls_projected_embedding
-        assert cls_projected_embedding is not None
+        # Only hidden_states[-1][:, 0, :] feeds the projection head (:98-99): the last layer's row-wise part runs on the CLS
+        # rows alone (text_encoder._forward, cls_only).  Same values as forward(...).cls_projected_embedding.
+        cls_projected_embedding, _ = self._encode(input_ids, attention_mask, cls_only=True)
         if normalize_embeddings:
             from ....functional import l2_normalize
             return l2_normalize(cls_projected_embedding)

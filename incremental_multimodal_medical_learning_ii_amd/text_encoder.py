@@ -70,7 +70,11 @@ class _Saved:
 
 
 def _forward(p: Sequence[torch.Tensor], ids: torch.Tensor, mask: Optional[torch.Tensor], n_layers: int, n_heads: int,
-             eps: float, save: bool):
+             eps: float, save: bool, cls_only: bool = False):
+    """cls_only: the caller consumes only the projected CLS embedding (`get_projected_text_embeddings`,
+    modelling_cxrbert.py:117-141 -> `hidden_states[-1][:, 0, :]`).  Everything in the LAST layer after the attention is
+    row-wise, so it runs on the N CLS rows instead of N*L tokens (output projection, both LayerNorms, the FFN: 75 % of that
+    layer's GEMM work); the returned `last` is then [N, H] (the CLS rows)."""
     N, L = ids.shape
     word, pos, typ, eg, eb = p[0:5]
     H = word.shape[1]
@@ -86,9 +90,13 @@ def _forward(p: Sequence[torch.Tensor], ids: torch.Tensor, mask: Optional[torch.
             raise RuntimeError("q/k/v parameters are not fused; call CXRBertModel.prepare_() after moving the model")
         qkv = K.linear_fwd(x, wqkv, bqkv)
         ctx, probs = K.attn_fwd(qkv, mask, N, L, n_heads, dH, save_probs=save)
-        t1 = K.linear_fwd(ctx, wo, bo, residual=x)
+        rows_cls = cls_only and i == n_layers - 1
+        if rows_cls:   # row 0 of every sequence: [N, H] views with row stride L*H
+            t1 = K.linear_fwd(ctx.view(N, L * H)[:, :H], wo, bo, residual=x.view(N, L * H)[:, :H])
+        else:
+            t1 = K.linear_fwd(ctx, wo, bo, residual=x)
         a, xhat1, rstd1 = K.residual_ln_fwd(t1, None, g1, b1, eps, save=save)
-        u_pre = torch.empty(N * L, wi.shape[0], dtype=torch.float32, device=x.device) if save else None
+        u_pre = torch.empty(t1.shape[0], wi.shape[0], dtype=torch.float32, device=x.device) if save else None
         u = K.linear_fwd(a, wi, bi, act=K.ACT_GELU, preact_out=u_pre)
         t2 = K.linear_fwd(u, wo2, bo2, residual=a)
         xn, xhat2, rstd2 = K.residual_ln_fwd(t2, None, g2, b2, eps, save=save)
@@ -99,7 +107,7 @@ def _forward(p: Sequence[torch.Tensor], ids: torch.Tensor, mask: Optional[torch.
             saved.append(s)
         x = xn
     wdh, bdh, gh, bh, wdo, bdo = p[5 + 16 * n_layers:]
-    cls = x.view(N, L * H)[:, :H]
+    cls = x if cls_only else x.view(N, L * H)[:, :H]
     h1_pre = torch.empty(N, wdh.shape[0], dtype=torch.float32, device=x.device)
     h1 = K.linear_fwd(cls, wdh, bdh, act=K.ACT_GELU, preact_out=h1_pre)
     h2, xhat_h, rstd_h = K.residual_ln_fwd(h1, None, gh, bh, 1e-12)
@@ -108,8 +116,9 @@ def _forward(p: Sequence[torch.Tensor], ids: torch.Tensor, mask: Optional[torch.
 
 
 def _backward(p: Sequence[torch.Tensor], ids: torch.Tensor, n_layers: int, n_heads: int, state, last, dproj, dlast,
-              need: Sequence[bool]):
-    """Returns the list of parameter gradients (same order as `p`).  `last` is the final hidden state [T,H]."""
+              need: Sequence[bool], cls_only: bool = False):
+    """Returns the list of parameter gradients (same order as `p`).  `last` is the final hidden state [T,H]
+    ([N,H], the CLS rows, when cls_only: the last layer's row-wise part then runs on those rows only)."""
     N, L = ids.shape
     xhat0, rstd0, saved, h1_pre, h2, xhat_h, rstd_h = state
     word, pos, typ, eg, eb = p[0:5]
@@ -123,10 +132,11 @@ def _backward(p: Sequence[torch.Tensor], ids: torch.Tensor, n_layers: int, n_hea
 
     base = 5 + 16 * n_layers
     wdh, bdh, gh, bh, wdo, bdo = p[base:]
+    R = N if cls_only else T          # rows of the last layer's row-wise part
     if dlast is not None:
-        dx = dlast.reshape(T, H).contiguous().clone()
+        dx = dlast.reshape(R, H).contiguous().clone()
     else:
-        dx = torch.zeros(T, H, dtype=torch.float32, device=dev)
+        dx = torch.zeros(R, H, dtype=torch.float32, device=dev)
     if dproj is not None:
         dproj = dproj.contiguous()
         grads[base + 4] = K.linear_bwd_weight(dproj, h2, new(wdo))
@@ -136,10 +146,10 @@ def _backward(p: Sequence[torch.Tensor], ids: torch.Tensor, n_layers: int, n_hea
         dh1 = K.residual_ln_bwd(dh2, xhat_h, rstd_h, gh, dgh, dbh)
         grads[base + 2], grads[base + 3] = dgh, dbh
         dh1p = K.gelu_bwd(dh1, h1_pre)
-        cls = last.view(N, L * H)[:, :H]                    # last_hidden_state[:, 0, :] (modelling_cxrbert.py:98-99)
+        cls = last if cls_only else last.view(N, L * H)[:, :H]   # last_hidden_state[:, 0, :] (modelling_cxrbert.py:98-99)
         grads[base + 0] = K.linear_bwd_weight(dh1p, cls, new(wdh))
         grads[base + 1] = K.colsum(dh1p, new(bdh))
-        K.linear_bwd_data(dh1p, wdh, out=dx.view(N, L * H)[:, :H], accumulate=True)
+        K.linear_bwd_data(dh1p, wdh, out=dx if cls_only else dx.view(N, L * H)[:, :H], accumulate=True)
     else:
         for j in range(6):
             grads[base + j] = torch.zeros_like(p[base + j])
@@ -160,16 +170,27 @@ def _backward(p: Sequence[torch.Tensor], ids: torch.Tensor, n_layers: int, n_hea
         dg1, db1 = new(g1), new(b1)
         dt1 = K.residual_ln_bwd(da, s.xhat1, s.rstd1, g1, dg1, db1)
         grads[o + 8], grads[o + 9] = dg1, db1
-        grads[o + 6] = K.linear_bwd_weight(dt1, s.ctx, new(wo))
-        grads[o + 7] = K.colsum(dt1, new(bo))
-        dctx = K.linear_bwd_data(dt1, wo)
+        rows_cls = cls_only and i == n_layers - 1
+        if rows_cls:   # dt1 holds the CLS rows only: its context rows are row 0 of every sequence, all other rows get no gradient
+            grads[o + 6] = K.linear_bwd_weight(dt1, s.ctx.view(N, L * H)[:, :H], new(wo))
+            grads[o + 7] = K.colsum(dt1, new(bo))
+            dctx = torch.zeros(T, H, dtype=torch.float32, device=dev)
+            K.linear_bwd_data(dt1, wo, out=dctx.view(N, L * H)[:, :H])
+        else:
+            grads[o + 6] = K.linear_bwd_weight(dt1, s.ctx, new(wo))
+            grads[o + 7] = K.colsum(dt1, new(bo))
+            dctx = K.linear_bwd_data(dt1, wo)
         dqkv = K.attn_bwd(s.qkv, s.probs, dctx, N, L, n_heads, H // n_heads)
         wqkv = _fused(wq, wk, wv)
         dwqkv = K.linear_bwd_weight(dqkv, s.x, torch.empty(3 * H, H, dtype=torch.float32, device=dev))
         dbqkv = K.colsum(dqkv, torch.empty(3 * H, dtype=torch.float32, device=dev))
         grads[o + 0], grads[o + 2], grads[o + 4] = dwqkv[0:H], dwqkv[H:2 * H], dwqkv[2 * H:3 * H]
         grads[o + 1], grads[o + 3], grads[o + 5] = dbqkv[0:H], dbqkv[H:2 * H], dbqkv[2 * H:3 * H]
-        dx = K.linear_bwd_data(dqkv, wqkv, residual=dt1)
+        if rows_cls:   # the residual branch x -> t1 exists for the CLS rows only
+            dx = K.linear_bwd_data(dqkv, wqkv)
+            dx.view(N, L * H)[:, :H].add_(dt1)
+        else:
+            dx = K.linear_bwd_data(dqkv, wqkv, residual=dt1)
         saved[i] = None  # free this layer's activations early
 
     deg, deb = new(eg), new(eb)
@@ -191,39 +212,40 @@ def _backward(p: Sequence[torch.Tensor], ids: torch.Tensor, n_layers: int, n_hea
 
 
 class CXRBertEncodeFn(torch.autograd.Function):
-    """(ids, mask, cfg, *params) -> (cls_projected_embedding [N,P], last_hidden_state [N,L,H])."""
+    """(ids, mask, cfg, cls_only, *params) -> (cls_projected_embedding [N,P], last_hidden_state [N,L,H], or [N,1,H] = its
+    CLS rows when cls_only)."""
 
     @staticmethod
-    def forward(ctx, ids, mask, n_layers, n_heads, eps, *params):
+    def forward(ctx, ids, mask, n_layers, n_heads, eps, cls_only, *params):
         ctx.set_materialize_grads(False)
         save = any(t.requires_grad for t in params)
         p = [t.detach() for t in params]
-        proj, last, state = _forward(p, ids, mask, n_layers, n_heads, eps, save)
+        proj, last, state = _forward(p, ids, mask, n_layers, n_heads, eps, save, cls_only)
         if save:
             ctx.state = state
-            ctx.cfg = (n_layers, n_heads)
+            ctx.cfg = (n_layers, n_heads, cls_only)
             ctx.ids = ids
             ctx.last = last
             ctx.params = p
             ctx.need = [t.requires_grad for t in params]
         N, L = ids.shape
-        return proj, last.view(N, L, -1)
+        return proj, last.view(N, 1 if cls_only else L, -1)
 
     @staticmethod
     def backward(ctx, dproj, dlast):
-        n_layers, n_heads = ctx.cfg
-        grads = _backward(ctx.params, ctx.ids, n_layers, n_heads, ctx.state, ctx.last, dproj, dlast, ctx.need)
+        n_layers, n_heads, cls_only = ctx.cfg
+        grads = _backward(ctx.params, ctx.ids, n_layers, n_heads, ctx.state, ctx.last, dproj, dlast, ctx.need, cls_only)
         ctx.state = None
         ctx.last = None
-        return (None, None, None, None, None) + tuple(g if n else None for g, n in zip(grads, ctx.need))
+        return (None, None, None, None, None, None) + tuple(g if n else None for g, n in zip(grads, ctx.need))
 
 
 def encode(params: Sequence[torch.Tensor], ids: torch.Tensor, mask: Optional[torch.Tensor], n_layers: int,
-           n_heads: int, eps: float = 1e-12) -> Tuple[torch.Tensor, torch.Tensor]:
+           n_heads: int, eps: float = 1e-12, cls_only: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     if ids.dtype != torch.int64:
         ids = ids.to(torch.int64)
     if mask is not None and mask.dtype != torch.int64:
         mask = mask.to(torch.int64)
     ids = ids.contiguous()
     mask = mask.contiguous() if mask is not None else None
-    return CXRBertEncodeFn.apply(ids, mask, n_layers, n_heads, eps, *params)
+    return CXRBertEncodeFn.apply(ids, mask, n_layers, n_heads, eps, bool(cls_only), *params)

@@ -286,6 +286,35 @@ def test_joint_step_vs_cpu_oracle():
                 assert rel(sd[k], v) < ptol, k
 
 
+def test_text_cls_only_last_layer_equals_full_path():
+    """`get_projected_text_embeddings` runs the last layer's row-wise part on the CLS rows only; values and every
+    parameter gradient must equal the full-sequence path (`forward(...).cls_projected_embedding`)."""
+    cfg = CXRBertConfig(vocab_size=300, hidden_size=128, num_attention_heads=2, intermediate_size=256,
+                        num_hidden_layers=3, max_position_embeddings=32)
+    model = CXRBertModel(cfg).eval()
+    syn.fill_module_(model)
+    model.to(DEV)
+    ids, mask = syn.synthetic_tokens(5, 17, vocab=300, seed=11, ragged=True)
+    ids, mask = ids.to(DEV), mask.to(DEV)
+    probe = T(syn._normal("cls_only.probe", (5, 128))).to(DEV)
+    grads = []
+    embs = []
+    for cls_only in (False, True):
+        model.zero_grad()
+        if cls_only:
+            e = model.get_projected_text_embeddings(ids, mask, normalize_embeddings=False)
+        else:
+            e = model(ids, mask, output_cls_projected_embedding=True, return_dict=True, output_mlm_logits=False).cls_projected_embedding
+        (e * probe).sum().backward()
+        embs.append(e.detach().clone())
+        grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert rel(embs[1], embs[0]) < 1e-5
+    assert grads[0].keys() == grads[1].keys()
+    for n in grads[0]:
+        if grads[0][n].abs().max() > 1e-7:
+            assert rel(grads[1][n], grads[0][n]) < 1e-4, n
+
+
 # ------------------------------------------------------------------------------------------------ BASELINE config 1
 def test_zero_shot_engine_config1():
     """ZERO_JOINT_BOUNDS-style zero-shot (BASELINE.json configs[0], scaled to 8 images): synthetic 224x224 images x 5
