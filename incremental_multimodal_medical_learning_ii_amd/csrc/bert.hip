@@ -425,7 +425,7 @@ extern "C" int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, i
   const size_t sh = (size_t)(3 * L * ALD + L * (L + 1)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)((3 * AL * (AD + 4) + AL * (AL + 1)) * sizeof(float)));
     attr_set = true;
   }
@@ -443,7 +443,7 @@ extern "C" int cxrk_attn_bwd(const float* qkv, const float* probs, const float* 
   const size_t sh = (size_t)(4 * L * ALD + 2 * L * (L + 1)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)((4 * AL * (AD + 4) + 2 * AL * (AL + 1)) * sizeof(float)));
     attr_set = true;
   }

@@ -403,7 +403,6 @@ __global__ __launch_bounds__(NTHREADS, (WM == 2 && WN == 2) ? 3 : 2) void gemm_x
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int r = lane & 31, h = lane >> 5;
 
   LA la; LB lb;
   la.init(pa, m0, tid);
