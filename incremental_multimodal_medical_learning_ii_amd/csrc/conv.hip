@@ -378,7 +378,7 @@ extern "C" int cxrk_conv_bn_act_fwd(const float* x, const float* w_scaled, const
   EpiParams ep{};
   ep.C = y; ep.ldc = Ko; ep.bias = shift; ep.R = residual; ep.ldr = Ko; ep.act = relu ? 1 : 0; ep.alpha = 1.f;
   int rc;
-  const bool tapwise = (C % BK == 0) && R * S <= 32;  // a K-tile inside one filter tap (everything but the stem)
+  const bool tapwise = (C % BK == 0) && R * S <= 32 && R <= 8;  // a K-tile inside one filter tap (everything but the stem)
   if (tapwise && use_wide256(M, Ko, K, 1, false, WIDE_MINK_FPROP)) {
     ConvIm2colKC<256, true, NT_WIDE>::P pa{x, g, M, K}; DenseKC<256, NT_WIDE>::P pb{w_scaled, (long)K, Ko, K};
     rc = launch_gemm_wide<ConvIm2colKC<256, true, NT_WIDE>, DenseKC<256, NT_WIDE>>(pa, pb, ep, M, Ko, K, 1, stream);
@@ -430,7 +430,7 @@ static int conv_bwd_data_impl(const float* dy, const float* w_scaled, const floa
                               const float* bn_sub, const float* bn_beta, const float* bn_beta2, hipStream_t stream) {
   CXRK_CHECK_ARG(dy && w_scaled && dx && N > 0 && C % 4 == 0 && Ko % 4 == 0 && aligned16(dy) && aligned16(w_scaled));
   CXRK_CHECK_ARG(stride == 1 || stride == 2);
-  if (Ko % BK != 0 || R * S > 32) return CXRK_ERR_UNSUPPORTED;  // the gather keeps a K-tile inside one filter tap
+  if (Ko % BK != 0 || R * S > 32 || R > 8) return CXRK_ERR_UNSUPPORTED;  // the gather keeps a K-tile inside one filter tap
   const ConvGeom g = make_geom(N, H, W, C, Ko, R, S, stride, pad);
   const long Ml = (long)N * H * W;
   CXRK_CHECK_ARG(Ml < (1L << 31));

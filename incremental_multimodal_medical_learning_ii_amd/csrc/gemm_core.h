@@ -161,7 +161,7 @@ __device__ __forceinline__ void gemm_epilogue64(f32x16 (&acc)[2][2], const EpiPa
 #pragma unroll
     for (int tg = 0; tg < 2; ++tg) {
       long rows[4]; bool live[4];
-      float4 pr[4], pa[4], ps[4];
+      float4 pr[4], pa[4];   // residual and ReLU / GELU' source; the rarer BatchNorm term is read in place (registers)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int rl = (tg * 4 + u) * 4 + rq;
@@ -173,11 +173,10 @@ __device__ __forceinline__ void gemm_epilogue64(f32x16 (&acc)[2][2], const EpiPa
           row = ((long)n_ * ep.rm_H + 2 * a_ + ep.rm_ph) * ep.rm_W + 2 * b_ + ep.rm_pw;
         }
         rows[u] = row;
-        pr[u] = pa[u] = ps[u] = zero4();
+        pr[u] = pa[u] = zero4();
         if (ep.vec && live[u]) {
           if (ep.R) pr[u] = *reinterpret_cast<const float4*>(ep.R + row * ep.ldr + col);
           if (ep.auxmode) pa[u] = *reinterpret_cast<const float4*>(ep.aux + row * ep.ldaux + col);
-          if (ep.bn_part && ep.bn_sub) ps[u] = *reinterpret_cast<const float4*>(ep.bn_sub + row * ep.bn_ldsub + col);
         }
       }
 #pragma unroll
@@ -203,7 +202,8 @@ __device__ __forceinline__ void gemm_epilogue64(f32x16 (&acc)[2][2], const EpiPa
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = ep.auxmode == 1 ? (ax[q] > 0.f ? v[q] : 0.f) : v[q] * gelu_erf_grad(ax[q]);
             if (ep.bn_part) {
-              const float sb[4] = {ps[u].x, ps[u].y, ps[u].z, ps[u].w};
+              float sb[4] = {0.f, 0.f, 0.f, 0.f};
+              if (ep.bn_sub) { const float4 s4 = *reinterpret_cast<const float4*>(ep.bn_sub + row * ep.bn_ldsub + col); sb[0] = s4.x; sb[1] = s4.y; sb[2] = s4.z; sb[3] = s4.w; }
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 bs[0][q] += v[q];

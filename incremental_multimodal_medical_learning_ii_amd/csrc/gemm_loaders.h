@@ -40,6 +40,24 @@ __device__ __forceinline__ unsigned masked_off(unsigned off, unsigned inv, int t
   return (__builtin_amdgcn_ubfe(inv, (unsigned)t, 1u) << 31) | off;
 }
 
+// Halo masks without data-dependent loops (a runtime-bounded loop inside the unrolled per-row loop makes the row index
+// dynamic and sends the loader's off[] / inv[] arrays to scratch memory).
+__device__ __forceinline__ unsigned low_bits(int k) { return k >= 32 ? 0xffffffffu : ((1u << k) - 1u); }
+// bits i in [0, n) that fall outside [lo, hi)   (0 <= lo, hi <= n after clamping)
+__device__ __forceinline__ unsigned outside_bits(int lo, int hi, int n) {
+  lo = min(max(lo, 0), n); hi = min(max(hi, 0), n);
+  return low_bits(lo) | (low_bits(n) & ~low_bits(hi));
+}
+// bit (r*S + s) = badr bit r | bads bit s, for r < R <= 8, R*S <= 32
+__device__ __forceinline__ unsigned tap_mask(unsigned badr, unsigned bads, int R, int S) {
+  const unsigned full = low_bits(S);
+  unsigned m = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+    if (r < R) m |= (((badr >> r) & 1u) ? full : bads) << (r * S);
+  return m;
+}
+
 // ---- LDS staging shared by the loaders -------------------------------------------------------------------------------
 // K-contiguous operand (k4 = tid & 7 -> 4 consecutive k, r0 = tid >> 3 -> row, +RP = NT / 8 rows per j)
 template <int NV, int LD, int RP>
@@ -171,18 +189,18 @@ struct ConvIm2colKC {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int row = idx0 + r0 + j * RP;
-      if (row < p.rows) {
-        const int wo = row % p.g.Wo; const int t = row / p.g.Wo; const int ho = t % p.g.Ho; const int n = t / p.g.Ho;
-        const int h0 = ho * p.g.stride - p.g.pad, w0 = wo * p.g.stride - p.g.pad;
-        off[j] = (unsigned)(((((n - n_first) * H + h0) * W + w0) * C + bias + (TAPWISE ? k4 * 4 : 0)) * 4);
-        if (TAPWISE) {
-          unsigned m = 0;
-          for (int r = 0; r < p.g.R; ++r)
-            for (int s = 0; s < S; ++s)
-              if ((unsigned)(h0 + r) >= (unsigned)H || (unsigned)(w0 + s) >= (unsigned)W) m |= 1u << (r * S + s);
-          inv[j] = m;
-        } else { hi0[j] = h0; wi0[j] = w0; }
-      } else { off[j] = 0; inv[j] = 0xffffffffu; hi0[j] = -(1 << 28); wi0[j] = 0; }
+      const bool in = row < p.rows;
+      const int rowc = in ? row : 0;   // every value below is computed for a valid row and then selected (no branches)
+      const int wo = rowc % p.g.Wo; const int t = rowc / p.g.Wo; const int ho = t % p.g.Ho; const int n = t / p.g.Ho;
+      const int h0 = ho * p.g.stride - p.g.pad, w0 = wo * p.g.stride - p.g.pad;
+      const unsigned o = (unsigned)(((((n - n_first) * H + h0) * W + w0) * C + bias + (TAPWISE ? k4 * 4 : 0)) * 4);
+      off[j] = in ? o : 0u;
+      if constexpr (TAPWISE) {   // tap (r,s) reads (h0 + r, w0 + s): inside the image for r in [-h0, H - h0), s in [-w0, W - w0)
+        const unsigned m = tap_mask(outside_bits(-h0, H - h0, p.g.R), outside_bits(-w0, W - w0, S), p.g.R, S);
+        inv[j] = in ? m : 0xffffffffu;
+      } else {
+        hi0[j] = in ? h0 : -(1 << 28); wi0[j] = in ? w0 : 0;
+      }
     }
   }
   __device__ __forceinline__ void load(int k0, float4 (&v)[NV], bool live = true) {
@@ -238,11 +256,8 @@ struct ConvDgradKC {
       if (row < p.rows) {
         const int wi = row % W; const int t = row / W; const int hi = t % H; const int n = t / H;
         off[j] = (unsigned)(((((n - n_first) * Ho + hi + pad) * Wo + wi + pad) * Ko + k4 * 4) * 4);
-        unsigned m = 0;
-        for (int r = 0; r < R; ++r)
-          for (int s = 0; s < S; ++s)
-            if ((unsigned)(hi + pad - r) >= (unsigned)Ho || (unsigned)(wi + pad - s) >= (unsigned)Wo) m |= 1u << (r * S + s);
-        inv[j] = m;
+        // tap (r,s) reads (hi + pad - r, wi + pad - s): inside for r in (hi + pad - Ho, hi + pad], s likewise
+        inv[j] = tap_mask(outside_bits(hi + pad - Ho + 1, hi + pad + 1, R), outside_bits(wi + pad - Wo + 1, wi + pad + 1, S), R, S);
       } else { off[j] = 0; inv[j] = 0xffffffffu; }
     }
   }
@@ -324,9 +339,11 @@ struct ConvDgradS2KC {
         const int b = row % p.Ws; const int q = row / p.Ws; const int a = q % p.Hs; const int n = q / p.Hs;
         off[j] = (unsigned)(((((n - n_first) * Ho + a) * Wo + b) * Ko + k4 * 4) * 4);
         unsigned m = 0;
-        for (int ir = 0; ir < t.nr; ++ir)
-          for (int is = 0; is < t.ns; ++is)
-            if (a + t.dr[ir] >= Ho || b + t.ds[is] >= Wo) m |= 1u << (ir * t.ns + is);
+#pragma unroll
+        for (int ir = 0; ir < 2; ++ir)
+#pragma unroll
+          for (int is = 0; is < 2; ++is)
+            if (ir < t.nr && is < t.ns && (a + t.dr[ir] >= Ho || b + t.ds[is] >= Wo)) m |= 1u << (ir * t.ns + is);
         inv[j] = m;
       } else { off[j] = 0; inv[j] = 0xffffffffu; }
     }
