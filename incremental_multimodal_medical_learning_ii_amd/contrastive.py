@@ -23,9 +23,12 @@ from . import optim as cxr_optim
 
 class JointContrastiveTrainer:
     def __init__(self, image_model: torch.nn.Module, text_model: torch.nn.Module, lr: float = 1e-4,
-                 temperature: float = 0.07, group=None, train_mlm_head: bool = False):
+                 temperature: float = 0.07, group=None, train_mlm_head: bool = False, two_streams: Optional[bool] = None):
         self.image_model, self.text_model = image_model, text_model
         self.temperature, self.group = temperature, group
+        import os
+        self.two_streams = (os.environ.get("CXRK_TWO_STREAMS", "1") != "0") if two_streams is None else bool(two_streams)
+        self._text_stream = None
         image_model.prepare_()
         text_model.prepare_()
         params = [p for n, p in image_model.named_parameters() if not n.startswith("encoder.encoder.fc.")]
@@ -42,8 +45,22 @@ class JointContrastiveTrainer:
             self.world = dist.get_world_size(group)
 
     def forward_loss(self, images: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        """The two encoders are independent up to the loss, so the text encoder runs on a second HIP stream: the tail of one
+        encoder's launch (its last, partly filled round of workgroups) overlaps the head of the other's.  Autograd replays
+        each encoder's backward on the stream its forward ran on and joins them again before `backward()` returns."""
+        if not (self.two_streams and images.is_cuda):
+            img = self.image_model(images)
+            txt = self.text_model.get_projected_text_embeddings(input_ids, attention_mask, normalize_embeddings=False)
+            return Fh.infonce_loss(img, txt, self.temperature, self.group)
+        if self._text_stream is None:
+            self._text_stream = torch.cuda.Stream(device=images.device)
+        cur = torch.cuda.current_stream(images.device)
+        self._text_stream.wait_stream(cur)                     # inputs, weights and the zeroed gradients are ready
+        with torch.cuda.stream(self._text_stream):
+            txt = self.text_model.get_projected_text_embeddings(input_ids, attention_mask, normalize_embeddings=False)
         img = self.image_model(images)
-        txt = self.text_model.get_projected_text_embeddings(input_ids, attention_mask, normalize_embeddings=False)
+        cur.wait_stream(self._text_stream)
+        txt.record_stream(cur)
         return Fh.infonce_loss(img, txt, self.temperature, self.group)
 
     def step(self, images: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:

@@ -100,13 +100,14 @@ def _label(la: str, lb: str, tile: str, M: int, N: int, K: int, splitk: int, kin
 
 
 class _Workspace:
-    """Grow-on-demand scratch buffer per device; reuse is safe because all kernels run stream-ordered."""
+    """Grow-on-demand scratch buffer per device and stream; reuse is safe because kernels of one stream run in order."""
 
     def __init__(self):
         self.bufs = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        key = (device.type, device.index)
+        # one buffer per (device, stream): the two encoders of the joint step run on two streams
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
         buf = self.bufs.get(key)
         if buf is None or buf.numel() * 4 < nbytes:
             n = max(int(nbytes * 1.25) // 4 + 64, 1 << 20)
