@@ -42,8 +42,8 @@ size_t cxrk_gemm_splitk_ws_bytes(int M, int N, int splitk);
 /* Split-K factor the library recommends for a weight-gradient shaped GEMM (M x N output, K = rows reduced over): enough
  * slabs to fill the chip with the tile the launch will take in the current precision mode. */
 int cxrk_gemm_wgrad_splitk(int M, int N, int K);
-/* 1 when a launch of this GEMM shape takes the 256x256 tile (reporting only).  kind: 0 plain epilogue / weight gradient,
- * 1 convolution forward, 2 convolution data gradient, 3 dense layer with a fused epilogue. */
+/* 1 when a launch of this GEMM shape takes the 256x256 tile (reporting only).  kind: 0 or 3 dense layer / weight gradient,
+ * 1 convolution forward, 2 convolution data gradient. */
 int cxrk_gemm_wide_tile(int M, int N, long K, int splitk, int kind);
 int cxrk_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                   float* C, long ldc, const float* bias, const float* R, long ldr, const float* aux, long ldaux,

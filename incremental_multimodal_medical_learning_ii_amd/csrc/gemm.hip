@@ -99,11 +99,10 @@ extern "C" int cxrk_gemm_wgrad_splitk(int M, int N, int K) {
   return (int)sk;
 }
 
-// 1 when a launch of this shape takes the 256x256 tile in the current precision mode.  kind: 0 = plain epilogue (dense
-// weight gradient / split-K / convolution weight gradient), 1 = convolution forward, 2 = convolution data gradient,
-// 3 = dense layer with a fused epilogue.  (Reporting only: lets the host label its launch timings by mainloop.)
+// 1 when a launch of this shape takes the 256x256 tile in the current precision mode.  kind: 0 / 3 = dense layer or weight
+// gradient (3 = with a fused epilogue; same policy), 1 = convolution forward, 2 = convolution data gradient.
+// (Reporting only: lets the host label its launch timings by mainloop.)
 extern "C" int cxrk_gemm_wide_tile(int M, int N, long K, int splitk, int kind) {
-  if (kind == 3) return wide_mode() == 2 && use_wide256(M, N, K, splitk);
   return use_wide256(M, N, K, splitk, false, kind == 1 ? WIDE_MINK_FPROP : (kind == 2 ? WIDE_MINK_DGRAD : WIDE_MINK_PLAIN));
 }
 
@@ -135,10 +134,11 @@ extern "C" int cxrk_gemm_f32(int transA, int transB, int M, int N, int K, const 
     ep.C2 = C2; ep.ldc2 = ldc2; ep.act = act;
   }
   int rc;
-  // 256x256 tile: only for plain epilogues (weight gradients, split-K slabs).  With a fused bias / GELU / residual epilogue
-  // the one-block-per-CU kernel exposes it and the step's forward and data-gradient GEMMs ran 3-7 % slower than on 128x128.
+  // 256x256 tile wherever the policy allows it.  (Alone on the GPU, launches with a fused bias / GELU / residual epilogue ran
+  // 3-7 % slower on it than on 128x128 -- one block per CU exposes the epilogue --, but in the step the other encoder's
+  // stream fills those phases and the larger tile wins: -1.4 % step time.)
 #define CXRK_TILES(LAT, LBT, pa_expr, pb_expr)                                                                    \
-  if ((plain || wide_mode() == 2) && use_wide256(M, N, K, splitk)) { LAT<256, NT_WIDE>::P pa = pa_expr; LBT<256, NT_WIDE>::P pb = pb_expr;       \
+  if (use_wide256(M, N, K, splitk)) { LAT<256, NT_WIDE>::P pa = pa_expr; LBT<256, NT_WIDE>::P pb = pb_expr;       \
     rc = launch_gemm_wide<LAT<256, NT_WIDE>, LBT<256, NT_WIDE>>(pa, pb, ep, M, N, K, splitk, stream); }           \
   else if (N <= 64) { LAT<256>::P pa = pa_expr; LBT<64>::P pb = pb_expr;                                               \
     rc = launch_gemm<LAT<256>, LBT<64>, 4, 1>(pa, pb, ep, M, N, K, splitk, stream); }                             \

@@ -584,9 +584,14 @@ static inline int stream_output(int M, int N, int splitk) { return (double)M * N
 inline int wide_mode() { static const int m = [] { const char* e = getenv("CXRK_WIDE"); return e ? atoi(e) : 1; }(); return m; }
 // min_k: shortest K loop (per split-K slab) for which the caller's kind of launch gains (measured per kind on the step's
 // shapes, scripts/layer_table.py: the heavier the fused epilogue, the longer the loop has to be to pay for exposing it).
-constexpr long WIDE_MINK_PLAIN = 512;    // dense layers, weight gradients (plain / bias / GELU epilogues)
-constexpr long WIDE_MINK_FPROP = 2048;   // convolution forward (shift + residual + ReLU)
-constexpr long WIDE_MINK_DGRAD = 4096;   // convolution data gradient (ReLU mask + fused BatchNorm sums)
+static inline long env_long(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
+#define WIDE_MINK_PLAIN (wide_mink(0))   // dense layers, weight gradients
+#define WIDE_MINK_FPROP (wide_mink(1))   // convolution forward (shift + residual + ReLU)
+#define WIDE_MINK_DGRAD (wide_mink(2))   // convolution data gradient (ReLU mask + fused BatchNorm sums)
+inline long wide_mink(int kind) {
+  static const long v[3] = {env_long("CXRK_MINK_PLAIN", 512), env_long("CXRK_MINK_FPROP", 2048), env_long("CXRK_MINK_DGRAD", 4096)};
+  return v[kind];
+}
 static inline bool use_wide256(int M, int N, long K, int splitk, bool force_fp32 = false, long min_k = WIDE_MINK_PLAIN) {
   if (gemm_precision_mode() != 1 || force_fp32 || 2.0 * M * N * (double)K < 1073741824.0) return false;
   const int mode = wide_mode();
