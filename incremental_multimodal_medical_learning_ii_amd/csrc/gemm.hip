@@ -85,7 +85,7 @@ extern "C" int cxrk_gemm_wgrad_splitk(int M, int N, int K) {
   const long maxk = K / (8 * BK) > 0 ? K / (8 * BK) : 1;
   if (gemm_precision_mode() == 1 && wide_mode() != 0 && M >= 256 && N >= 256) {
     const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256);
-    long sk = (512 + tiles / 2) / tiles;
+    long sk = 512 / tiles;   // floor: two full rounds of 256 blocks at most (one block over would cost a third round)
     if (sk > maxk) sk = maxk;
     if (sk < 1) sk = 1;
     if (sk > 512) sk = 512;

@@ -314,3 +314,85 @@ def test_adam_sgd_weight_reset():
     K.weight_reset(nd, old.to(DEV), 0.3, counters)
     assert torch.equal(nd.cpu(), ref)
     assert counters[0].item() == cnt
+
+
+# ------------------------------------------------------------------------------------------------ 256x256 tile
+def _with_precision(mode):
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        old = _cxr_lib.get_precision()
+        _cxr_lib.set_precision(mode)
+        try:
+            yield
+        finally:
+            _cxr_lib.set_precision(old)
+    return cm()
+
+
+def test_wide_tile_dense_at_policy_shapes():
+    """Shapes at which the library's OWN policy picks the 256x256 kernel in split-bf16 (`cxrk_gemm_wide_tile`), checked
+    against PyTorch-CPU fp32 and against the exact-fp32 mainloop of the same entry point: forward with a fused
+    bias + GELU + pre-activation copy, data gradient with a residual and a ReLU mask, weight gradient through split-K."""
+    lib = _cxr_lib.load()
+    M, N, Kd = 4096, 4096, 512                      # 256 tiles = one full round of the 256 CUs
+    x, w, b = rnd(M, Kd, scale=0.5), rnd(N, Kd, seed=1, scale=0.5), rnd(N, seed=2)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    with _with_precision("split_bf16"):
+        assert lib.cxrk_gemm_wide_tile(M, N, Kd, 1, 3) == 1 and lib.cxrk_gemm_wide_tile(M, N, Kd, 1, 0) == 1
+        pre = torch.empty(M, N, device=DEV)
+        y = K.linear_fwd(xd, wd, bias=bd, act=K.ACT_GELU, preact_out=pre)
+        ref = x @ w.T + b
+        close(pre, ref, tol=3e-4, what="wide fwd preact")
+        close(y, F.gelu(ref), tol=3e-4, what="wide fwd gelu")
+        dy, r, aux = rnd(M, N, seed=3, scale=0.5), rnd(M, Kd, seed=4), rnd(M, Kd, seed=5)
+        M2, N2, K2 = M, 4096, N                      # dx[M, 4096] = dy[M, N] @ w2[N, 4096]
+        w2 = rnd(N, N2, seed=6, scale=0.5)
+        r2, aux2 = rnd(M, N2, seed=7), rnd(M, N2, seed=8)
+        assert lib.cxrk_gemm_wide_tile(M2, N2, K2, 1, 3) == 1
+        dx = K.linear_bwd_data(dy.to(DEV), w2.to(DEV), aux=aux2.to(DEV), auxmode=K.AUX_RELU_MASK, residual=r2.to(DEV))
+        close(dx, (dy @ w2 + r2) * (aux2 > 0), tol=3e-4, what="wide dgrad")
+        # weight gradient: small output, long reduction -> split-K slabs on the wide tile
+        T, No, Ki = 32768, 1024, 768
+        g, a = rnd(T, No, seed=9, scale=0.3), rnd(T, Ki, seed=10, scale=0.3)
+        sk = lib.cxrk_gemm_wgrad_splitk(No, Ki, T)
+        assert sk > 1 and lib.cxrk_gemm_wide_tile(No, Ki, T, sk, 0) == 1
+        dw = torch.empty(No, Ki, device=DEV)
+        close(K.linear_bwd_weight(g.to(DEV), a.to(DEV), dw), g.T @ a, tol=3e-4, what="wide wgrad")
+        y_x3 = y.clone()
+    with _with_precision("fp32"):
+        close(y_x3, K.linear_fwd(xd, wd, bias=bd, act=K.ACT_GELU), tol=3e-4, what="wide vs exact fp32 mainloop")
+
+
+def test_wide_tile_conv_at_policy_shapes():
+    """3x3 convolution (256 -> 512 channels, 14x14, batch 136) at which the policy picks the 256x256 kernel for the
+    forward and for the weight gradient; reference = the exact-fp32 mainloop of the same entry points (itself checked
+    against PyTorch in test_conv_bn_relu_fwd_bwd)."""
+    lib = _cxr_lib.load()
+    N, H, C, Ko, R = 136, 14, 256, 512, 3
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, H, H, C, generator=g).to(DEV)
+    w = (torch.randn(Ko, R, R, C, generator=g) / math.sqrt(C * R * R)).to(DEV)
+    sh = (0.1 * torch.randn(Ko, generator=g)).to(DEV)
+    res = torch.randn(N, H, H, Ko, generator=g).to(DEV)
+    dy = torch.randn(N, H, H, Ko, generator=g).to(DEV)
+    sc = torch.ones(Ko, device=DEV); zero = torch.zeros(Ko, device=DEV)
+
+    def run():
+        y = torch.empty(N, H, H, Ko, device=DEV)
+        K.conv_fwd(x, w, sh, res, y, N, H, H, C, Ko, R, R, 1, 1, True)
+        dw = torch.empty_like(w); dg = torch.empty(Ko, device=DEV); db = torch.empty(Ko, device=DEV)
+        K.conv_bwd_params(x, dy, w, sc, sc, zero, zero, None, None, dw, dg, db, False, N, H, H, C, C, Ko, R, R, 1, 1)
+        return y, dw
+
+    with _with_precision("split_bf16"):
+        M = N * H * H
+        assert lib.cxrk_gemm_wide_tile(M, Ko, R * R * C, 1, 1) == 1
+        sk = lib.cxrk_gemm_wgrad_splitk(Ko, R * R * C, M)
+        assert lib.cxrk_gemm_wide_tile(Ko, R * R * C, M, sk, 0) == 1
+        y1, dw1 = run()
+    with _with_precision("fp32"):
+        y0, dw0 = run()
+    close(y1, y0, tol=3e-4, what="wide conv fwd vs exact fp32")
+    close(dw1, dw0, tol=3e-4, what="wide conv wgrad vs exact fp32")
