@@ -365,6 +365,13 @@ extern "C" int cxrk_bn_fold(const float* w, const float* gamma, const float* bet
   return CXRK_OK;
 }
 
+// The convolution gathers address a block's rows with 32-bit byte offsets from the first image the tile touches
+// (gemm_loaders.h): a 256-row tile spans at most 256 / (Ho*Wo) + 2 images of the gathered tensor, which must stay < 2 GiB.
+static bool tile_span_ok(long rows_per_image, long image_elems) {
+  const long images = 256 / (rows_per_image > 0 ? rows_per_image : 1) + 2;
+  return images * image_elems * 4 < (1L << 31);
+}
+
 extern "C" int cxrk_conv_bn_act_fwd(const float* x, const float* w_scaled, const float* shift, const float* residual,
                                     float* y, int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad,
                                     int relu, hipStream_t stream) {
@@ -375,6 +382,7 @@ extern "C" int cxrk_conv_bn_act_fwd(const float* x, const float* w_scaled, const
   const long Ml = (long)N * g.Ho * g.Wo;
   CXRK_CHECK_ARG(Ml < (1L << 31));
   const int M = (int)Ml, K = R * S * C;
+  if (!tile_span_ok((long)g.Ho * g.Wo, (long)H * W * C)) return CXRK_ERR_UNSUPPORTED;
   EpiParams ep{};
   ep.C = y; ep.ldc = Ko; ep.bias = shift; ep.R = residual; ep.ldr = Ko; ep.act = relu ? 1 : 0; ep.alpha = 1.f;
   int rc;
@@ -435,6 +443,7 @@ static int conv_bwd_data_impl(const float* dy, const float* w_scaled, const floa
   const long Ml = (long)N * H * W;
   CXRK_CHECK_ARG(Ml < (1L << 31));
   const int M = (int)Ml, K = R * S * Ko;
+  if (!tile_span_ok((long)(H / stride) * (W / stride), (long)g.Ho * g.Wo * Ko)) return CXRK_ERR_UNSUPPORTED;
   EpiParams ep{};
   ep.C = dx; ep.ldc = C; ep.R = residual; ep.ldr = C; ep.alpha = 1.f;
   if (relu_src) { ep.aux = relu_src; ep.ldaux = C; ep.auxmode = 1; }
@@ -568,6 +577,7 @@ extern "C" int cxrk_conv_bn_act_bwd_params(const float* x, const float* dy, cons
   const long Kl = (long)N * g.Ho * g.Wo;
   CXRK_CHECK_ARG(Kl < (1L << 31));
   const int Kred = (int)Kl, Nc = R * S * Cpad;
+  if ((long)H * W * Cpad * 4 * 3 >= (1L << 31)) return CXRK_ERR_UNSUPPORTED;  // a K-tile of 32 pixels spans <= 3 images
   int sk = wgrad_splitk(Ko, Nc, Kl);
   if (ws == nullptr || ws_bytes < (size_t)sk * Ko * Nc * sizeof(float)) return CXRK_ERR_WS;
   EpiParams ep{};

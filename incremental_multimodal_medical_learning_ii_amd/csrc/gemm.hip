@@ -119,6 +119,8 @@ extern "C" int cxrk_gemm_f32(int transA, int transB, int M, int N, int K, const 
   CXRK_CHECK_ARG(transA ? (M % 4 == 0) : (K % 4 == 0));
   CXRK_CHECK_ARG(transB ? (K % 4 == 0) : (N % 4 == 0));
   CXRK_CHECK_ARG(!(auxmode != 0 && aux == nullptr));
+  // the loaders address a tile with 32-bit byte offsets from its origin (gemm_loaders.h): 256 rows x ld must stay < 2 GiB
+  if (lda >= (1L << 20) || ldb >= (1L << 20)) return CXRK_ERR_UNSUPPORTED;
   if (splitk < 1) splitk = 1;
   EpiParams ep{};
   ep.alpha = alpha; ep.slab_stride = 0;
