@@ -205,6 +205,26 @@ def main():
     dt = float(t.item())
     final_loss = float(loss.item()) if loss is not None else float("nan")
 
+    # Evidence that the split-bf16 contractions meet the fp32 bar at THIS size: the same weights and batch through the
+    # forward in both precisions (no optimiser step; all ranks take part in the loss collectives).
+    precision_check = None
+    if not args.no_secondary:
+        vals = {}
+        with torch.no_grad():
+            for mode in ("fp32", "split_bf16"):
+                cxr_lib.set_precision(mode)
+                img_e = trainer.image_model(images)
+                txt_e = trainer.text_model.get_projected_text_embeddings(ids, mask, normalize_embeddings=False)
+                from incremental_multimodal_medical_learning_ii_amd import functional as Fh
+                vals[mode] = (img_e.clone(), txt_e.clone(), Fh.infonce_loss(img_e, txt_e, args.temperature).clone())
+        cxr_lib.set_precision(args.precision)
+        a, b = vals["fp32"], vals["split_bf16"]
+        rel = lambda x, y: float(((x - y).abs().max() / y.abs().max().clamp_min(1e-30)).item())
+        precision_check = {"what": "forward of the bench batch and weights in split_bf16 vs exact fp32 contractions (max abs diff / max abs)",
+                           "image_embedding": rel(b[0], a[0]), "text_embedding": rel(b[1], a[1]),
+                           "loss": abs(float(b[2]) - float(a[2])) / abs(float(a[2])), "bar": 1e-3}
+        log(f"precision check: {precision_check}")
+
     secondary = None
     if not args.no_secondary:   # same step in the other contraction precision (2 warm-up + 3 timed steps)
         other = "fp32" if args.precision == "split_bf16" else "split_bf16"
@@ -295,6 +315,8 @@ def main():
                                               "ms_per_step": tot_ms / prof_steps}}
         if secondary is not None:
             out["other_precision"] = secondary
+        if precision_check is not None:
+            out["precision_check"] = precision_check
         if world == 1 and not args.no_cpu_baseline:   # the CPU leg runs at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch, args.seq_len, args.image_size, args.temperature)
