@@ -575,7 +575,10 @@ inline int& gemm_precision_mode() { static int mode = 0; return mode; }
 
 // Outputs that cannot stay in the 32 MiB of L2 anyway are stored non-temporally, so that they do not evict the operand
 // panels the co-running tiles are re-reading (dense 32768x3072x768: +10 % with the 256x256 tile).
-static inline int stream_output(int M, int N, int splitk) { return (double)M * N * 4.0 * (splitk > 1 ? splitk : 1) >= 64.0 * 1048576.0; }
+static inline int stream_output(int M, int N, int splitk) {
+  static const double thr = [] { const char* e = getenv("CXRK_NT_MB"); return (e ? atof(e) : 64.0) * 1048576.0; }();  // tuning override
+  return (double)M * N * 4.0 * (splitk > 1 ? splitk : 1) >= thr;
+}
 
 // 256x256-tile policy.  CXRK_WIDE (environment, read once): 0 = never, 1 (default) = where it pays, 2 = wherever the
 // precision mode allows it (test coverage on small shapes).  "Pays": split-bf16 launch, both tile dimensions filled, a K
