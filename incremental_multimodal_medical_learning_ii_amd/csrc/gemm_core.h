@@ -583,7 +583,8 @@ static inline int stream_output(int M, int N, int splitk) {
 // 256x256-tile policy.  CXRK_WIDE (environment, read once): 0 = never, 1 (default) = where it pays, 2 = wherever the
 // precision mode allows it (test coverage on small shapes).  "Pays": split-bf16 launch, both tile dimensions filled, a K
 // loop long enough to amortise the exposed prologue / epilogue of a one-block-per-CU kernel, and a tile count that fills
-// the 256 CUs in whole rounds to at least 80 %.
+// the 256 CUs in whole rounds to at least 60 % (the other encoder's stream fills a partial round: 80 -> 70 % was worth 3 % of
+// the step, below 60 % nothing more).
 inline int wide_mode() { static const int m = [] { const char* e = getenv("CXRK_WIDE"); return e ? atoi(e) : 1; }(); return m; }
 // min_k: shortest K loop (per split-K slab) for which the caller's kind of launch gains (measured per kind on the step's
 // shapes, scripts/layer_table.py: the heavier the fused epilogue, the longer the loop has to be to pay for exposing it).
@@ -592,7 +593,7 @@ static inline long env_long(const char* name, long dflt) { const char* e = geten
 #define WIDE_MINK_FPROP (wide_mink(1))   // convolution forward (shift + residual + ReLU)
 #define WIDE_MINK_DGRAD (wide_mink(2))   // convolution data gradient (ReLU mask + fused BatchNorm sums)
 inline long wide_mink(int kind) {
-  static const long v[3] = {env_long("CXRK_MINK_PLAIN", 512), env_long("CXRK_MINK_FPROP", 2048), env_long("CXRK_MINK_DGRAD", 4096)};
+  static const long v[3] = {env_long("CXRK_MINK_PLAIN", 512), env_long("CXRK_MINK_FPROP", 512), env_long("CXRK_MINK_DGRAD", 1024)};
   return v[kind];
 }
 static inline bool use_wide256(int M, int N, long K, int splitk, bool force_fp32 = false, long min_k = WIDE_MINK_PLAIN) {
@@ -604,7 +605,8 @@ static inline bool use_wide256(int M, int N, long K, int splitk, bool force_fp32
   if (kper < min_k) return false;
   const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256) * (splitk > 1 ? splitk : 1);
   const long rounds = (tiles + 255) / 256;
-  return tiles * 10 >= rounds * 256 * 8;
+  static const long eff_pct = env_long("CXRK_WIDE_EFF", 60);   // tuning override: minimum round efficiency in percent
+  return tiles * 100 >= rounds * 256 * eff_pct;
 }
 
 template <class LA, class LB>
