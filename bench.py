@@ -12,6 +12,9 @@ weak scaling for N>1: 8192 global at N=8 = BASELINE config 5).  fp32 storage and
 contractions run in split-bf16 (three bf16 MFMAs per product, fp32 accumulate, ~2^-16 relative; `--precision fp32` =
 exact fp32 MFMA, measured beside it as `other_precision`).  Synthetic data resident in HBM before the timed region,
 seeded random-init weights.
+The two encoders run on two HIP streams (contrastive.JointContrastiveTrainer); the per-kernel profile behind `roofline` is
+taken over two extra single-stream steps after the timed region (see the comment there), `precision_check` compares the
+split-bf16 forward with the exact-fp32 one on the bench batch.
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
 from __future__ import annotations
