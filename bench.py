@@ -118,8 +118,55 @@ def cpu_baseline(batch: int, seq_len: int, image_size: int, tau: float):
                       f"the negligible B^2 logits"}
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_cmd(n_ranks: int, argv, port: int):
+    """Command line that runs this script as `n_ranks` ranks of one node (one process per GPU over RCCL)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def spawn_ranks(n_ranks: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (this parent never touches the
+    GPU, so nothing that initialised HIP is ever replaced or re-executed), pass rank 0's JSON line through on stdout and
+    return the launcher's exit status (non-zero when any rank failed)."""
+    import subprocess
+    cmd = launch_cmd(n_ranks, argv, _free_port())
+    print(f"[bench] --gpus {n_ranks} without WORLD_SIZE: launching {n_ranks} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n_ranks)))
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+def selftest_rank() -> None:
+    """CXRK_BENCH_SELFTEST=1: exercise the launcher, rendezvous and collectives only (no GPU work), so the spawn path can be
+    tested on a CPU box with gloo.  Rank 0 prints a JSON line like the real run does."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(os.environ.get("CXRK_DIST_BACKEND", "gloo"))
+    t = torch.ones(1) * (dist.get_rank() + 1)
+    dist.all_reduce(t)
+    w = dist.get_world_size()
+    assert float(t) == w * (w + 1) / 2
+    dist.barrier()
+    if dist.get_rank() == 0:
+        print(json.dumps({"selftest": True, "rccl_ranks": w, "n_gpus": w}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("CXRK_BENCH_SELFTEST") == "1":
+        return selftest_rank()
     import faulthandler
     faulthandler.enable()
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)   # a stuck phase shows where it is stuck
@@ -139,8 +186,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: using {world} rank(s)", file=sys.stderr)
+    if args.gpus != world:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` without a launcher: it starts the ranks itself)")
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
@@ -252,7 +300,8 @@ def main():
         value = world * B * args.steps / dt
         out = {
             "metric": "contrastive train-step images/sec at global batch 1024; 1/2/4/8-GPU scaling",
-            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "images/sec", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp32" if args.precision == "fp32" else "bf16x3",
             "data": "synthetic",

@@ -242,10 +242,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     float o[2][2];
     dot2x2(Qs, Ks, ALD, d4, i0, i1, j0, j1, o);
     const bool m0 = mask && mask[(long)b * L + j0] == 0, m1 = mask && mask[(long)b * L + j1] == 0;
-    Ps[i0 * LP + j0] = m0 ? -INFINITY : o[0][0] * scale;
-    Ps[i0 * LP + j1] = m1 ? -INFINITY : o[0][1] * scale;
-    Ps[i1 * LP + j0] = m0 ? -INFINITY : o[1][0] * scale;
-    Ps[i1 * LP + j1] = m1 ? -INFINITY : o[1][1] * scale;
+    // HuggingFace adds finfo(float32).min to the masked scores (score + min == min in fp32): a finite value, so that a
+    // sequence whose mask is all zeros gets a uniform attention row, as in the reference, instead of exp(-inf - -inf) = NaN
+    constexpr float MASKED = -3.4028234663852886e38f;
+    Ps[i0 * LP + j0] = m0 ? MASKED : o[0][0] * scale;
+    Ps[i0 * LP + j1] = m1 ? MASKED : o[0][1] * scale;
+    Ps[i1 * LP + j0] = m0 ? MASKED : o[1][0] * scale;
+    Ps[i1 * LP + j1] = m1 ? MASKED : o[1][1] * scale;
   }
   __syncthreads();
   // softmax: 4 lanes per row

@@ -190,6 +190,14 @@ class _InfoNCE(torch.autograd.Function):
         dist_on = group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         img, txt = img.detach().contiguous(), txt.detach().contiguous()
         B, D = img.shape
+        if tuple(txt.shape) != (B, D):
+            raise ValueError(f"infonce_loss: image embeddings are {tuple(img.shape)} but text embeddings {tuple(txt.shape)}")
+        world_ = dist.get_world_size(group) if dist_on else 1
+        if (B * world_) % 4 != 0 or D % 4 != 0:
+            # the backward GEMMs contract over the global batch with 16-byte row accesses; fail HERE, before any collective
+            # is issued, not inside loss.backward() with the other ranks already waiting in the gradient all-reduce
+            raise ValueError(f"infonce_loss: global batch {B * world_} (= {B} rows x {world_} ranks) and embedding size {D} must be "
+                             f"multiples of 4 (drop or pad the ragged last batch)")
         ih, inorm = K.l2norm_fwd(img)
         th, tnorm = K.l2norm_fwd(txt)
         if dist_on:

@@ -86,6 +86,7 @@ class ImageModel(nn.Module):
         self.train()
         self._specs, self._blocks = IE.resnet50_specs("encoder.encoder.", joint_feature_size)
         self._hot: Optional[Tuple[List[nn.Parameter], List[torch.Tensor]]] = None
+        self._bn: Optional[List[nn.Module]] = None
         if pretrained_model_path is not None:
             if not isinstance(pretrained_model_path, (str, Path)):
                 raise TypeError(f"Expected a string or Path, got {type(pretrained_model_path)}")
@@ -93,8 +94,8 @@ class ImageModel(nn.Module):
             self.load_state_dict(state_dict)
 
     def train(self, mode: bool = True, my_freeze: bool = False) -> Any:
-        """Switch between training and evaluation modes (`model.py:131-139`).  BatchNorm always normalises with its
-        running statistics on this path (see `image_encoder`), which is what every reference call site does."""
+        """Switch between training and evaluation modes (`model.py:131-139`).  The forward refuses to run while a BatchNorm
+        layer is in training mode (see `_run`): use `.eval()` or `my_freeze=True`, as every reference call site does."""
         super().train(mode=mode)
         if my_freeze:
             print("freezing resnet encoder and projector")
@@ -118,12 +119,27 @@ class ImageModel(nn.Module):
             self._hot = ([named[n] for n in IE.param_names(self._specs)], [bufs[n] for n in IE.buffer_names(self._specs)])
         return self._hot
 
+    def _check_mode(self) -> None:
+        """Train-mode BatchNorm (batch statistics + running-stat updates, what `self.train()` at the end of the reference's
+        constructor selects) is NOT implemented: this path normalises with the running statistics, the only mode the
+        reference ever runs the encoder in (chexpert-get-embedding.py:41-42).  Refuse instead of silently computing
+        eval-mode numbers for a model that says it is in training mode."""
+        if self._bn is None:
+            self._bn = [m for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+        if any(m.training for m in self._bn):
+            raise NotImplementedError("ImageModel: BatchNorm layers are in training mode (batch statistics), which the HIP path "
+                                      "does not implement; call .eval() (or .train(my_freeze=True)) first -- gamma/beta and all "
+                                      "filters still receive gradients in eval mode")
+
     def _run(self, x: torch.Tensor, want_patch: bool):
         if not x.is_cuda:
             raise RuntimeError("ImageModel runs on the MI355X only: move the model and inputs to 'cuda' "
                                "(there is no CPU fallback; the CPU oracle lives in oracle/ and is test-only)")
         if x.dtype != torch.float32:
             raise ValueError(f"expected fp32 images, got {x.dtype}")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"ImageModel expects [B,3,H,W] input (ExpandChannels, transforms.py:12-38), got {tuple(x.shape)}")
+        self._check_mode()
         self.prepare_()
         params, bufs = self._tensors()
         meta = (self._specs, self._blocks, len(params), want_patch)

@@ -11,7 +11,6 @@ from dataclasses import dataclass
 from typing import Any, List, Optional, Tuple, Union
 
 import torch
-import torch.nn.functional as F  # noqa: F401  (kept for API parity; not used for arithmetic)
 from torch import Tensor as T
 from torch import nn
 from transformers import BertForMaskedLM
@@ -85,12 +84,21 @@ class CXRBertModel(BertForMaskedLM):
             TE.fuse_qkv_(att.query.bias, att.key.bias, att.value.bias)
         return self
 
+    def _check_mode(self) -> None:
+        """Dropout is not implemented; the reference only ever runs the text model in eval mode
+        (text/inference_engine.py:63 asserts it).  Refuse rather than silently skip the dropout of a training-mode model."""
+        cfg = self.config
+        if self.training and (getattr(cfg, "hidden_dropout_prob", 0.0) > 0 or getattr(cfg, "attention_probs_dropout_prob", 0.0) > 0):
+            raise NotImplementedError("CXRBertModel is in training mode with dropout > 0, which the HIP path does not implement; "
+                                      "call .eval() (parameters still receive gradients) or set the dropout probabilities to 0")
+
     def _encode(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], cls_only: bool = False):
         if not input_ids.is_cuda:
             raise RuntimeError("CXRBertModel runs on the MI355X only: move the model and inputs to 'cuda' "
                                "(there is no CPU fallback; the CPU oracle lives in oracle/ and is test-only)")
         self.prepare_()
         cfg = self.config
+        self._check_mode()
         if getattr(cfg, "hidden_act", "gelu") != "gelu":
             raise NotImplementedError(f"hidden_act={cfg.hidden_act!r}: only erf-GELU (CXR-BERT) is implemented")
         return TE.encode(self._hot_params(), input_ids, attention_mask, cfg.num_hidden_layers,

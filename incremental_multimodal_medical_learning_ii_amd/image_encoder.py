@@ -259,9 +259,27 @@ def relu_decisions(state) -> List[torch.Tensor]:
     return [(a > 0).permute(0, 3, 1, 2).contiguous().cpu() for a in acts]
 
 
+_capture: Optional[list] = None
+
+
+class capture_relu_decisions:
+    """Test hook: `with capture_relu_decisions() as cap:` makes every grad-enabled image-encoder forward inside the block
+    append its ReLU decisions (`relu_decisions`, CPU bool tensors) to `cap`.  Nothing is kept outside the block, and the
+    saved-activation state itself is never referenced from module level (it lives on the autograd node only)."""
+
+    def __enter__(self):
+        global _capture
+        self._old, _capture = _capture, []
+        return _capture
+
+    def __exit__(self, *exc):
+        global _capture
+        _capture = self._old
+        return False
+
+
 class ImageEncodeFn(torch.autograd.Function):
     """(x[N,3,H,W], meta, *params, *buffers) -> (global embedding [N,J], projected patch embeddings NHWC or None)."""
-    last_state = None
 
     @staticmethod
     def forward(ctx, x, meta, *tensors):
@@ -274,7 +292,8 @@ class ImageEncodeFn(torch.autograd.Function):
         emb, patch, state = _forward(specs, blocks, p, b, x.detach(), save, want_patch)
         if save:
             ctx.state, ctx.p, ctx.b, ctx.meta = state, p, b, meta
-            ImageEncodeFn.last_state = state  # weak convenience handle for the parity tests (overwritten every call)
+            if _capture is not None:
+                _capture.append(relu_decisions(state))
         ctx.mark_non_differentiable(*[])
         if patch is None:
             patch = emb.new_empty(0)
@@ -287,5 +306,4 @@ class ImageEncodeFn(torch.autograd.Function):
             dpatch = None
         grads = _backward(specs, blocks, ctx.p, ctx.b, ctx.state, demb, dpatch)
         ctx.state = None
-        ImageEncodeFn.last_state = None
         return (None, None) + tuple(grads) + (None,) * len(ctx.b)

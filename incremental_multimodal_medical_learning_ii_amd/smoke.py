@@ -6,8 +6,20 @@ import torch
 
 
 def run_smoke(verbose: bool = True) -> None:
+    """Both contraction precisions of the library: split-bf16 (what bench.py reports) and exact fp32."""
     if not torch.cuda.is_available():
         raise RuntimeError("smoke() needs an MI355X (cuda:0)")
+    from . import _lib
+    old = _lib.get_precision()
+    try:
+        for mode in ("split_bf16", "fp32"):
+            _lib.set_precision(mode)
+            _run_one(mode, verbose)
+    finally:
+        _lib.set_precision(old)
+
+
+def _run_one(mode: str, verbose: bool) -> None:
     from . import image_encoder as IE
     from . import synthetic as syn
     from .contrastive import JointContrastiveTrainer
@@ -29,8 +41,9 @@ def run_smoke(verbose: bool = True) -> None:
 
     tr = JointContrastiveTrainer(im.to(dev), tm.to(dev), lr=1e-4, temperature=tau)
     tr.optimizer.zero_grad()
-    loss = tr.forward_loss(images.to(dev), ids.to(dev), mask.to(dev))
-    masks = IE.relu_decisions(IE.ImageEncodeFn.last_state)
+    with IE.capture_relu_decisions() as cap:
+        loss = tr.forward_loss(images.to(dev), ids.to(dev), mask.to(dev))
+    masks = cap[0]
     loss.backward()
     g_img = dict(im.named_parameters())["encoder.encoder.layer2.0.conv2.weight"].grad.detach().cpu().clone()
     g_txt = dict(tm.named_parameters())["bert.encoder.layer.0.intermediate.dense.weight"].grad.detach().cpu().clone()
@@ -62,6 +75,6 @@ def run_smoke(verbose: bool = True) -> None:
 
     e_p = max(rel_q(im.state_dict()[k], v) for k, v in ip.items() if v.requires_grad)
     if verbose:
-        print(f"[smoke] loss hip={loss.item():.6f} oracle={loss_ref.item():.6f} rel={e_loss:.2e}; grad rel err image={e_gi:.2e} "
+        print(f"[smoke {mode}] loss hip={loss.item():.6f} oracle={loss_ref.item():.6f} rel={e_loss:.2e}; grad rel err image={e_gi:.2e} "
               f"text={e_gt:.2e}; params after Adam rel={e_p:.2e}; relu decisions flipped={pol.flips}/{pol.count}")
     assert e_loss < 1e-3 and e_gi < 1e-3 and e_gt < 1e-3 and e_p < 1e-3, (e_loss, e_gi, e_gt, e_p)

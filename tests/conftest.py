@@ -22,6 +22,27 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+PRECISIONS = ("fp32", "split_bf16")
+
+
+def pytest_generate_tests(metafunc):
+    """Every test that uses the `precision` fixture (all `-m gpu` parity modules do, through `pytestmark`) runs once per
+    contraction precision of the library: exact fp32 MFMA and split-bf16 (the mode bench.py reports)."""
+    if "precision" in metafunc.fixturenames:
+        metafunc.parametrize("precision", PRECISIONS, indirect=True)
+
+
+@pytest.fixture
+def precision(request):
+    from incremental_multimodal_medical_learning_ii_amd import _lib
+    old = _lib.get_precision()
+    _lib.set_precision(request.param)
+    try:
+        yield request.param
+    finally:
+        _lib.set_precision(old)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("precision")]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B_GLOBAL, L, TAU, IMG = 8, 16, 0.07, 64
@@ -48,8 +48,10 @@ def _probe(tr):
     return p[:: max(1, p.numel() // 4096)].detach().cpu().numpy(), float(p.double().sum().item())
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, precision):
     sys.path.insert(0, ROOT)
+    from incremental_multimodal_medical_learning_ii_amd import _lib
+    _lib.set_precision(precision)           # a spawned rank starts from the library default, not the parent's mode
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -67,10 +69,10 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_matches_single_process_global_batch(tmp_path):
+def test_two_rank_step_matches_single_process_global_batch(tmp_path, precision):
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), precision), nprocs=world, join=True)
     tr, images, ids, mask = _build()
     assert tr.world == 1
     loss = tr.step(images.to("cuda"), ids.to("cuda"), mask.to("cuda"))

@@ -5,7 +5,7 @@ import os
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("precision")]
 
 from incremental_multimodal_medical_learning_ii_amd import Trainer as TR  # noqa: E402
 from incremental_multimodal_medical_learning_ii_amd import drivers, embedding_precompute, synthetic as syn  # noqa: E402

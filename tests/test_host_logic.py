@@ -83,6 +83,26 @@ def test_models_fail_loudly_on_cpu():
         ImageModel("resnet18", 128)
 
 
+def test_training_mode_is_refused_not_silently_replaced_by_eval_semantics():
+    """The reference constructor leaves ImageModel in train mode (model.py:119): batch-statistic BatchNorm, which this path
+    does not implement -> it must raise, not run eval-mode arithmetic.  Same for dropout in CXRBertModel."""
+    im = get_biovil_resnet(None)
+    assert im.training
+    with pytest.raises(NotImplementedError, match="training mode"):
+        im._check_mode()
+    im.eval()._check_mode()
+    im.train(my_freeze=True)._check_mode()                      # reference :131-139: encoder + projector frozen in eval
+    cfg = CXRBertConfig(vocab_size=64, hidden_size=32, num_attention_heads=2, intermediate_size=64, num_hidden_layers=1,
+                        max_position_embeddings=16)
+    tm = CXRBertModel(cfg).train()
+    with pytest.raises(NotImplementedError, match="dropout"):
+        tm._check_mode()
+    tm.eval()._check_mode()
+    cfg0 = CXRBertConfig(vocab_size=64, hidden_size=32, num_attention_heads=2, intermediate_size=64, num_hidden_layers=1,
+                         max_position_embeddings=16, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    CXRBertModel(cfg0).train()._check_mode()                    # nothing to drop: train mode is exact
+
+
 def test_tokenizer_and_text_input_contract():
     tok = SyntheticTokenizer(1000)
     out = tok.batch_encode_plus(["No pleural effusion", "cardiomegaly"])

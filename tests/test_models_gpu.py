@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("precision")]
 
 from incremental_multimodal_medical_learning_ii_amd import functional as Fh  # noqa: E402
 from incremental_multimodal_medical_learning_ii_amd import optim as cxr_optim  # noqa: E402
@@ -137,10 +137,11 @@ def test_image_model_forward_backward(golden_dir):
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()}
     model.to(DEV).eval()
     x = syn.synthetic_images(2, 224, seed=27)
-    emb = model(x.to(DEV))
+    with IE.capture_relu_decisions() as cap:
+        emb = model(x.to(DEV))
     assert emb.shape == (2, 128)
     assert rel(emb, g["emb"]) < TOL, rel(emb, g["emb"])                      # forward vs the committed fixture
-    masks = IE.relu_decisions(IE.ImageEncodeFn.last_state)
+    masks = cap[0]
     probe = T(g["probe"])
     (emb * probe.to(DEV)).sum().backward()
     named = dict(model.named_parameters())
@@ -251,8 +252,9 @@ def test_joint_step_vs_cpu_oracle():
     # device: one full step (forward, InfoNCE, hand-written backward, fused Adam)
     tr = JointContrastiveTrainer(im.to(DEV), tm.to(DEV), lr=1e-4, temperature=tau)
     tr.optimizer.zero_grad()
-    loss = tr.forward_loss(images.to(DEV), ids.to(DEV), mask.to(DEV))
-    masks = IE.relu_decisions(IE.ImageEncodeFn.last_state)
+    with IE.capture_relu_decisions() as cap:
+        loss = tr.forward_loss(images.to(DEV), ids.to(DEV), mask.to(DEV))
+    masks = cap[0]
     loss.backward()
     grads_dev = {("i", n): p.grad.detach().clone() for n, p in im.named_parameters() if p.grad is not None}
     grads_dev.update({("t", n): p.grad.detach().clone() for n, p in tm.named_parameters() if p.grad is not None})

@@ -7,7 +7,7 @@ import math
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("precision")]
 
 from incremental_multimodal_medical_learning_ii_amd import functional as Fh  # noqa: E402
 from incremental_multimodal_medical_learning_ii_amd import kernels as K  # noqa: E402
@@ -43,6 +43,9 @@ def test_infonce_structure_at_global_batch_1024():
     # rows everywhere the logits are constant and loss = ln(B)
     ones = torch.ones(B, D, device=DEV)
     assert abs(Fh.infonce_loss(ones, ones, 1.0).item() - math.log(B)) < 1e-4
+    # a ragged last batch is refused in the forward, before any collective, not inside backward()
+    with pytest.raises(ValueError, match="multiples of 4"):
+        Fh.infonce_loss(I.detach()[:1022], T.detach()[:1022], tau)
 
 
 def test_text_encoder_batch_independence_and_padding_invariance():

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("precision")]
 
 from incremental_multimodal_medical_learning_ii_amd import Trainer as TR  # noqa: E402
 from incremental_multimodal_medical_learning_ii_amd import synthetic as syn  # noqa: E402
