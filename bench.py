@@ -161,6 +161,61 @@ def selftest_rank() -> None:
     dist.destroy_process_group()
 
 
+def secondary_metrics(args, dev, trainer, images, ids, mask, step_ms):
+    """SURVEY.md §8(d) / BASELINE.md §3 side measurements (N = 1 only; none of them is `value`)."""
+    from incremental_multimodal_medical_learning_ii_amd import functional as Fh
+    from incremental_multimodal_medical_learning_ii_amd import optim as cxr_optim
+    from incremental_multimodal_medical_learning_ii_amd import synthetic as syn
+    from incremental_multimodal_medical_learning_ii_amd.models import myMLP
+    out = {}
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    # (1) the reference's own step (T-ref): two adapters on pre-computed embeddings, 10 prompt vectors, pos-neg BCE, Adam
+    for B in (1024, 6144):
+        embs, labels, bert_out = (t.to(dev) for t in syn.synthetic_adapter_batch(B, seed=29))
+        ia, ta = myMLP().to(dev), myMLP().to(dev)
+        opt = cxr_optim.Adam(list(ta.parameters()) + list(ia.parameters()), lr=1e-4)
+
+        def ref_step():
+            opt.zero_grad()
+            pv = Fh.group_mean(ta(bert_out.reshape(40, 128)), 10, 4)
+            loss, _ = Fh.posneg_bce_loss(Fh.pairwise_cosine_similarity(ia(embs), pv), labels)
+            loss.backward()
+            opt.step()
+        dt = timed(ref_step, 30)
+        out[f"adapter_step_b{B}"] = {"ms_per_step": dt * 1e3, "embeddings_per_sec": B / dt,
+                                     "cpu_reference_ms": {1024: 15.7, 6144: 41.7}[B], "note": "reference-faithful step (Trainer.py:537-601); CPU figure from BASELINE.md §2 (8 threads, survey container)"}
+    # (2) embedding pre-compute at the reference's operating point (chexpert-get-embedding.py:48-74): 512x512, frozen encoder
+    x512 = syn.synthetic_images(64, 512, seed=31).to(dev)
+    with torch.no_grad():
+        dt = timed(lambda: trainer.image_model(x512), 3)
+    out["embedding_precompute_512px_b64"] = {"images_per_sec": 64 / dt, "ms_per_batch": dt * 1e3}
+    del x512
+    # (3) ragged prompts (lengths ~U{8..32}, right-padded): same step, attention masked
+    rid, rmask = syn.synthetic_tokens(ids.shape[0], ids.shape[1], seed=33, ragged=True)
+    rid, rmask = rid.to(dev), rmask.to(dev)
+    dt = timed(lambda: trainer.step(images, rid, rmask), 3)
+    out["ragged_tokens"] = {"ms_per_step": dt * 1e3, "images_per_sec": ids.shape[0] / dt}
+    # (4) PCIe-inclusive rate: the same batch copied from pinned host memory before every step, not overlapped
+    himg = images.cpu().pin_memory()
+    hid, hmask = ids.cpu().pin_memory(), mask.cpu().pin_memory()
+
+    def pcie_step():
+        trainer.step(himg.to(dev, non_blocking=True), hid.to(dev, non_blocking=True), hmask.to(dev, non_blocking=True))
+    dt = timed(pcie_step, 3)
+    out["pcie_inclusive"] = {"ms_per_step": dt * 1e3, "images_per_sec": ids.shape[0] / dt,
+                             "note": "host -> device copy of every batch inside the step, serialised with it (worst case; a copy stream hides it)"}
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -201,14 +256,19 @@ def main():
     log(f"building models (world={world}, batch/gpu={args.batch_per_gpu})")
     from incremental_multimodal_medical_learning_ii_amd import _lib as cxr_lib
     cxr_lib.set_precision(args.precision)
-    torch.manual_seed(27)                       # identical replicas on every rank
     im = get_biovil_resnet(None).eval()         # BN on running statistics (the reference's only mode)
     tm = CXRBertModel(CXRBertConfig()).eval()   # dropout inactive
+    syn.fill_module_(im)                        # name-keyed deterministic weights, non-trivial BN statistics: identical replicas
+    syn.fill_module_(tm)                        # on every rank, and a loss that actually moves (the parity tests use the same fill)
     trainer = JointContrastiveTrainer(im.to(dev), tm.to(dev), lr=1e-4, temperature=args.temperature)
     B = args.batch_per_gpu
-    images = syn.synthetic_images(B, args.image_size, seed=27 + rank).to(dev)
-    ids, mask = syn.synthetic_tokens(B, args.seq_len, seed=28 + rank)
-    ids, mask = ids.to(dev), mask.to(dev)
+    NB = 4                                      # resident batches the steps rotate through
+    batches = []
+    for j in range(NB):
+        img = syn.synthetic_images(B, args.image_size, seed=27 + 101 * j + rank).to(dev)
+        ids, mask = syn.synthetic_tokens(B, args.seq_len, seed=28 + 101 * j + rank)
+        batches.append((img, ids.to(dev), mask.to(dev)))
+    images, ids, mask = batches[0]
 
     def sync():
         torch.cuda.synchronize()
@@ -216,11 +276,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log("models + synthetic batch resident on the GPU; warm-up")
+    log(f"models + {NB} synthetic batches resident on the GPU; warm-up")
     loss = None
+    losses = []
     for i in range(args.warmup):
-        loss = trainer.step(images, ids, mask)
+        loss = trainer.step(*batches[i % NB])
         torch.cuda.synchronize()
+        losses.append(float(loss))
         log(f"warm-up step {i + 1}/{args.warmup} done, loss {float(loss):.4f}, "
             f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     sync()
@@ -228,13 +290,15 @@ def main():
     single_stream = not trainer.two_streams
     if prof and single_stream:
         K.profiler.start()
+    step_losses = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = trainer.step(images, ids, mask)
+    for i in range(args.steps):
+        step_losses.append(trainer.step(*batches[(args.warmup + i) % NB]))
     sync()
     dt = time.perf_counter() - t0
     K.profiler.stop()
-    log(f"timed region: {args.steps} steps in {dt:.2f} s")
+    losses += [float(x) for x in step_losses]
+    log(f"timed region: {args.steps} steps in {dt:.2f} s; loss {losses[0]:.4f} -> {losses[-1]:.4f}")
     prof_steps = args.steps
     if prof and not single_stream:
         # Per-kernel durations for the roofline: with the two encoders on two streams their kernels co-run, and an event
@@ -245,8 +309,8 @@ def main():
         K.profiler.start()
     if not single_stream and not args.no_roofline:
         trainer.two_streams = False
-        for _ in range(2):
-            trainer.step(images, ids, mask)
+        for j in range(2):
+            trainer.step(*batches[j % NB])
         sync()
         K.profiler.stop()
         trainer.two_streams = True
@@ -254,46 +318,66 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    final_loss = float(loss.item()) if loss is not None else float("nan")
+    final_loss = losses[-1]
 
-    # Evidence that the split-bf16 contractions meet the fp32 bar at THIS size: the same weights and batch through the
-    # forward in both precisions (no optimiser step; all ranks take part in the loss collectives).
+    # Evidence that the split-bf16 contractions meet the fp32 bar at THIS size: the same weights and batch through forward AND
+    # backward in both precisions (no optimiser step; all ranks take part in the loss collectives).  Gradients are compared by
+    # norm-relative error: the two modes take different sides of ~1e-5 of the ReLU kinks.
     precision_check = None
     if not args.no_secondary:
         vals = {}
-        with torch.no_grad():
-            for mode in ("fp32", "split_bf16"):
-                cxr_lib.set_precision(mode)
-                img_e = trainer.image_model(images)
-                txt_e = trainer.text_model.get_projected_text_embeddings(ids, mask, normalize_embeddings=False)
-                from incremental_multimodal_medical_learning_ii_amd import functional as Fh
-                vals[mode] = (img_e.clone(), txt_e.clone(), Fh.infonce_loss(img_e, txt_e, args.temperature).clone())
+        probe_names = ("encoder.encoder.layer4.2.conv3.weight", "encoder.encoder.layer1.0.conv1.weight")
+        tprobe = "bert.encoder.layer.11.intermediate.dense.weight"
+        inamed, tnamed = dict(trainer.image_model.named_parameters()), dict(trainer.text_model.named_parameters())
+        for mode in ("fp32", "split_bf16"):
+            cxr_lib.set_precision(mode)
+            trainer.optimizer.zero_grad()
+            ls = trainer.forward_loss(images, ids, mask)
+            ls.backward()
+            with torch.no_grad():
+                ie = trainer.image_model(images[:64]).clone()
+                te = trainer.text_model.get_projected_text_embeddings(ids[:64], mask[:64], normalize_embeddings=False).clone()
+            vals[mode] = (ie, te, ls.detach().clone(), [inamed[n].grad.detach().clone() for n in probe_names], tnamed[tprobe].grad.detach().clone())
+        trainer.optimizer.zero_grad()
         cxr_lib.set_precision(args.precision)
         a, b = vals["fp32"], vals["split_bf16"]
         rel = lambda x, y: float(((x - y).abs().max() / y.abs().max().clamp_min(1e-30)).item())
-        precision_check = {"what": "forward of the bench batch and weights in split_bf16 vs exact fp32 contractions (max abs diff / max abs)",
+        nrel = lambda x, y: float(((x - y).norm() / y.norm().clamp_min(1e-30)).item())
+        precision_check = {"what": "bench batch and weights through forward + backward in split_bf16 vs exact fp32 contractions "
+                                   "(embeddings / loss: max abs diff / max abs; gradients: ||diff|| / ||fp32||)",
                            "image_embedding": rel(b[0], a[0]), "text_embedding": rel(b[1], a[1]),
-                           "loss": abs(float(b[2]) - float(a[2])) / abs(float(a[2])), "bar": 1e-3}
+                           "loss": abs(float(b[2]) - float(a[2])) / abs(float(a[2])),
+                           "grad_image_layer4_conv3": nrel(b[3][0], a[3][0]), "grad_image_layer1_conv1": nrel(b[3][1], a[3][1]),
+                           "grad_text_layer11_ffn": nrel(b[4], a[4]), "bar": 1e-3}
+        del vals
         log(f"precision check: {precision_check}")
 
     secondary = None
-    if not args.no_secondary:   # same step in the other contraction precision (2 warm-up + 3 timed steps)
+    if not args.no_secondary:   # same step in the other contraction precision, the full --steps (2 warm-up)
         other = "fp32" if args.precision == "split_bf16" else "split_bf16"
         cxr_lib.set_precision(other)
-        for _ in range(2):
-            trainer.step(images, ids, mask)
+        for j in range(2):
+            trainer.step(*batches[j % NB])
         sync()
         t1 = time.perf_counter()
-        for _ in range(3):
-            trainer.step(images, ids, mask)
+        for j in range(args.steps):
+            trainer.step(*batches[j % NB])
         sync()
         d2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(d2, op=dist.ReduceOp.MAX)
-        secondary = {"precision": other, "value": world * B * 3 / float(d2.item()), "unit": "images/sec",
-                     "ms_per_step": float(d2.item()) / 3 * 1e3, "steps": 3}
+        secondary = {"precision": other, "value": world * B * args.steps / float(d2.item()), "unit": "images/sec",
+                     "ms_per_step": float(d2.item()) / args.steps * 1e3, "steps": args.steps}
         cxr_lib.set_precision(args.precision)
         log(f"secondary measurement ({other}): {secondary['ms_per_step']:.1f} ms/step")
+
+    side = None
+    if world == 1 and not args.no_secondary:
+        try:
+            side = secondary_metrics(args, dev, trainer, images, ids, mask, dt / args.steps * 1e3)
+            log(f"side measurements: {json.dumps(side)}")
+        except Exception as e:  # never lose the headline over a side measurement
+            side = {"error": repr(e)}
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -309,13 +393,16 @@ def main():
                                    "-> InfoNCE over the global batch -> backward through both encoders -> fused Adam "
                                    "(BASELINE config 3 at N=1: batch 1024 on one MI355X; config 5 at N=8: global 8192)",
                        "global_batch": world * B, "batch_per_gpu": B, "seq_len": args.seq_len, "image_size": args.image_size,
-                       "temperature": args.temperature, "parallelism": f"dp{world}", "weights": "seeded random init",
+                       "temperature": args.temperature, "parallelism": f"dp{world}",
+                       "weights": "name-keyed deterministic fill (synthetic.fill_module_), non-trivial BN statistics",
+                       "batches": f"{NB} resident synthetic batches, rotated",
                        "batchnorm": "running statistics (eval mode), gamma/beta trained",
                        "precision": args.precision,
-                       "precision_note": "split_bf16: every large GEMM / convolution takes a*b as hi*hi + hi*lo + lo*hi with "
-                                         "hi/lo = bf16 halves of the fp32 operand (~2^-16 relative per product); the parity suite "
-                                         "(1e-3 relative on embeddings, loss, gradients) passes in both modes; fp32 = exact fp32 MFMA"},
-            "final_loss": final_loss,
+                       "precision_note": "split_bf16: activations / gradients / weights that feed a contraction are stored as bf16 hi+lo "
+                                         "planes (4 B per element) and every product is hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 "
+                                         "accumulation (~2^-16 relative); the parity suite (1e-3 relative on embeddings, loss, gradients) "
+                                         "runs in both modes; fp32 = exact fp32 MFMA"},
+            "final_loss": final_loss, "loss_trace": [round(x, 5) for x in losses],
             "model_tflops_per_s": FLOP_PER_PAIR_STEP * world * B * args.steps / dt / 1e12,
         }
         if prof:
@@ -328,9 +415,11 @@ def main():
                 secs = d["ms"] * 1e-3
                 tflops = d["flops"] / secs / 1e12
                 gbps = d["bytes"] / secs / 1e9
-                peak_fl = PEAK_BF16_MFMA_TFLOPS if key.startswith("gemm_x3") else PEAK_FP32_MFMA_TFLOPS
-                # price the dominant kernel against BOTH roofs and report the one it sits closer to (the binding one)
-                frac_mfma, frac_hbm = tflops / peak_fl, gbps / PEAK_HBM_GBS
+                bf16 = key.startswith("gemm_x3") or key.startswith("gemm_pw")
+                peak_fl = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+                # price the dominant kernel against BOTH roofs and report the one it sits closer to (the binding one).  The
+                # split-bf16 mainloops execute 3 bf16 MFMAs per algorithmic product: their MFMA roof for algorithmic FLOPs is peak / 3.
+                frac_mfma, frac_hbm = tflops / (peak_fl / 3.0 if bf16 else peak_fl), gbps / PEAK_HBM_GBS
                 tot_ms = sum(v["ms"] for v in summ.values())
                 tot_fl = sum(v["flops"] for v in summ.values())
                 tot_by = sum(v["bytes"] for v in summ.values())
@@ -340,16 +429,15 @@ def main():
                     traffic = pmc["kernels"].get(key, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-                mfma_note = ("algorithmic 2*M*N*K FLOPs; the split-bf16 mainloop executes 3 bf16 MFMAs per product (3x this rate on "
-                             "the matrix pipe), priced against the dense bf16 peak") if key.startswith("gemm_x3") else \
-                            "exact fp32 MFMA, priced against the fp32 matrix peak"
+                mfma_note = ("algorithmic 2*M*N*K FLOPs against the dense bf16 MFMA peak / 3 (the split-bf16 mainloop executes 3 bf16 "
+                             "MFMAs per product)") if bf16 else "exact fp32 MFMA, priced against the fp32 matrix peak"
                 hbm = frac_hbm >= frac_mfma
                 out["roofline"] = {"bound": "hbm" if hbm else "mfma",
-                                   "achieved": gbps if hbm else tflops, "peak": PEAK_HBM_GBS if hbm else peak_fl,
+                                   "achieved": gbps if hbm else tflops, "peak": PEAK_HBM_GBS if hbm else (peak_fl / 3.0 if bf16 else peak_fl),
                                    "unit": "GB/s" if hbm else "TFLOP/s", "frac": frac_hbm if hbm else frac_mfma,
                                    "traffic": traffic, "kernel": key,
-                                   "note": ("algorithmic bytes: every operand and fused side input (ReLU source, residual, BatchNorm "
-                                            "terms) read once + the output written once, fp32; summed over the launches of this "
+                                   "note": ("algorithmic bytes: every operand and fused side input (residual, ReLU bit mask) read once + "
+                                            "the output written once, 4 B per element (1/8 B for masks); summed over the launches of this "
                                             "instantiation / their HIP-event time") if hbm else mfma_note,
                                    "launches_per_step": d["launches"] / prof_steps,
                                    "profiled": ("the timed region" if single_stream else
@@ -359,7 +447,8 @@ def main():
                                    "gflop_per_launch": d["flops"] / d["launches"] / 1e9,
                                    "algorithmic_mb_per_launch": d["bytes"] / d["launches"] / 1e6,
                                    "other_bound": {"bound": "mfma" if hbm else "hbm", "achieved": tflops if hbm else gbps,
-                                                   "peak": peak_fl if hbm else PEAK_HBM_GBS, "unit": "TFLOP/s" if hbm else "GB/s",
+                                                   "peak": (peak_fl / 3.0 if bf16 else peak_fl) if hbm else PEAK_HBM_GBS,
+                                                   "unit": "TFLOP/s" if hbm else "GB/s",
                                                    "frac": frac_mfma if hbm else frac_hbm, "note": mfma_note if hbm else ""},
                                    "family": {"kernel": "gemm_*_kernel<*> (all MFMA mainloop instantiations)",
                                               "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
@@ -369,6 +458,8 @@ def main():
             out["other_precision"] = secondary
         if precision_check is not None:
             out["precision_check"] = precision_check
+        if side is not None:
+            out["secondary"] = side
         if world == 1 and not args.no_cpu_baseline:   # the CPU leg runs at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch, args.seq_len, args.image_size, args.temperature)

@@ -41,7 +41,7 @@ extern "C" {
 size_t cxrk_gemm_splitk_ws_bytes(int M, int N, int splitk);
 /* Split-K factor the library recommends for a weight-gradient shaped GEMM (M x N output, K = rows reduced over): enough
  * slabs to fill the chip with the tile the launch will take in the current precision mode. */
-int cxrk_gemm_wgrad_splitk(int M, int N, int K);
+int cxrk_gemm_wgrad_splitk(int M, int N, int K, int planes);
 /* 1 when a launch of this GEMM shape takes the 256x256 tile (reporting only).  kind: 0 or 3 dense layer / weight gradient,
  * 1 convolution forward, 2 convolution data gradient. */
 int cxrk_gemm_wide_tile(int M, int N, long K, int splitk, int kind);
@@ -50,10 +50,24 @@ int cxrk_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, l
                   int auxmode, float* C2, long ldc2, int act, float alpha, int accumulate, int splitk, float* ws,
                   size_t ws_bytes, hipStream_t stream);
 
+/* The same contraction on planes operands (see "Storage formats" below): A and B are planes; the output is fp32 (C) or planes
+ * (Cp), the residual fp32 (R) or planes (Rp).  auxmode 2 = multiply by gelu'(aux) (aux fp32), 3 = multiply by the ReLU decision
+ * bits `maskin`; `maskout` (with act 1) receives the decision bits of this launch's ReLU.  transA && transB is not provided. */
+int cxrk_gemm_pl(int transA, int transB, int M, int N, int K, const void* A, long lda, long aplane, const void* B, long ldb,
+                 long bplane, float* C, void* Cp, long ldc, long cplane, const float* bias, const float* R, const void* Rp,
+                 long ldr, long rplane, const float* aux, long ldaux, int auxmode, const unsigned char* maskin, long ldmaskin,
+                 unsigned char* maskout, long ldmaskout, float* C2, long ldc2, int act, float alpha, int accumulate, int splitk,
+                 float* ws, size_t ws_bytes, hipStream_t stream);
+/* fp32 tensor -> planes (weights once per step, inputs of the path) and back (host-side consumers, tests); n % 8 == 0. */
+int cxrk_split_planes(const float* x, long n, void* out, long plane, hipStream_t stream);
+int cxrk_merge_planes(const void* x, long plane, long n, float* out, hipStream_t stream);
+
 /* out[cols] (+)= alpha * sum_rows X[rows, cols] — bias gradients, BN beta gradients, position/type embedding grads. */
 size_t cxrk_colsum_ws_bytes(long rows, int cols);
 int cxrk_colsum(const float* X, long ldx, long rows, int cols, float* out, float alpha, int accumulate, float* ws,
                 size_t ws_bytes, hipStream_t stream);
+int cxrk_colsum_pl(const void* X, long ldx, long plane, long rows, int cols, float* out, float alpha, int accumulate, float* ws,
+                   size_t ws_bytes, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * conv_bn_act — torchvision Bottleneck conv + eval-mode BatchNorm + ReLU (+ residual) as used by
@@ -62,36 +76,49 @@ int cxrk_colsum(const float* X, long ldx, long rows, int cols, float* out, float
  *               scale = gamma*rstd, shift = beta - mean*scale, rstd = rsqrt(var+eps).
  * fwd:        y = relu?( conv(x, w_scaled) + shift + residual? )
  * bwd_data:   dx = (relu_src>0)? * ( conv^T(dy, w_scaled) + residual? )        (dy already masked by its own ReLU)
- * bn_bwd_reduce: sumdy[c] = sum dy,  sumdyy[c] = sum dy * (y - sub - beta[c])   (y - sub = the BN output where dy != 0)
- * bwd_params: dW = scale * wgrad(x, dy);  dbeta = sumdy;  dgamma = sumdyy / gamma
- *             (when gamma/sumdyy are NULL or gamma == 0: rstd*(<w,wgrad> - mean*sumdy))
+ * bwd_params: dW = scale * wgrad(x, dy);  dbeta = sumdy = sum dy;
+ *             dgamma = sum dy * xhat = rstd * (<w, wgrad(x, dy)> - mean * sumdy): taken from the raw weight gradient the
+ *             call forms anyway (no activation is re-read, gamma is never divided by).
+ *
+ * Storage formats.  The fp32 entry points take fp32 tensors.  The `_pl` entry points take "planes" tensors: x stored as two
+ * bf16 planes hi = bf16(x), lo = bf16(x - hi) of the same shape, the lo plane `*plane` ELEMENTS behind the hi plane (4 bytes
+ * per element like fp32; pointers are `void*`).  They are what the encoders use in split-bf16 mode: the MFMA mainloops then
+ * load operands without any conversion work.  ReLU decisions travel as bit masks: byte [pixel][channel / 8], bit channel % 8.
  */
 int cxrk_bn_fold(const float* w, const float* gamma, const float* beta, const float* rmean, const float* rvar,
                  float eps, int Ko, int taps, int C, int Cpad, float* w_scaled, float* scale, float* shift,
                  float* rstd, hipStream_t stream);
+int cxrk_bn_fold_pl(const float* w, const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                    float eps, int Ko, int taps, int C, int Cpad, void* w_scaled, long wplane, float* scale, float* shift,
+                    float* rstd, hipStream_t stream);
 int cxrk_conv_bn_act_fwd(const float* x, const float* w_scaled, const float* shift, const float* residual, float* y,
                          int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad, int relu,
                          hipStream_t stream);
+/* y (and the optional residual) are planes; in_planes = 1: x and w_scaled are planes too, 0: they are fp32 (the stem).
+ * maskout (optional, needs relu) receives the ReLU decision bits of y. */
+int cxrk_conv_bn_act_fwd_pl(const void* x, long xplane, const void* w_scaled, long wplane, int in_planes, const float* shift,
+                            const void* residual, long rplane, void* y, long yplane, unsigned char* maskout, int N, int H,
+                            int W, int C, int Ko, int R, int S, int stride, int pad, int relu, hipStream_t stream);
+/* sums (optional, [C]) = column sums of dx: the BatchNorm beta gradient of the unit that produced relu_src / maskin (dx is
+ * that unit's masked output gradient), reduced in the data-gradient epilogue; needs ws of
+ * cxrk_conv_bwd_data_colsum_ws_bytes().  Not for 1x1 stride-2 filters. */
+size_t cxrk_conv_bwd_data_colsum_ws_bytes(int N, int H, int W, int C, int stride);
 int cxrk_conv_bn_act_bwd_data(const float* dy, const float* w_scaled, const float* residual, const float* relu_src,
                               float* dx, int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad,
-                              hipStream_t stream);
-/* bwd_data + the BN channel sums (cxrk_bn_bwd_reduce's outputs, plus the downsample unit's) of the unit that produced
- * relu_src, fused into the data-gradient epilogue: sums[0]=sum dx, sums[1]=sum dx*(relu_src-bn_sub-bn_beta),
- * sums[2]=sum dx*(bn_sub-bn_beta2).  Not for 1x1 stride-2 filters. */
-size_t cxrk_conv_bwd_data_bnsum_ws_bytes(int N, int H, int W, int C, int stride);
-int cxrk_conv_bn_act_bwd_data_bnsum(const float* dy, const float* w_scaled, const float* residual, const float* relu_src,
-                                    float* dx, int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad,
-                                    const float* bn_sub, const float* bn_beta, const float* bn_beta2, float* sums,
-                                    float* ws, size_t ws_bytes, hipStream_t stream);
+                              float* sums, float* ws, size_t ws_bytes, hipStream_t stream);
+int cxrk_conv_bn_act_bwd_data_pl(const void* dy, long dyplane, const void* w_scaled, long wplane, const void* residual,
+                                 long rplane, const unsigned char* maskin, void* dx, long dxplane, int N, int H, int W, int C,
+                                 int Ko, int R, int S, int stride, int pad, float* sums, float* ws, size_t ws_bytes,
+                                 hipStream_t stream);
 size_t cxrk_conv_wgrad_ws_bytes(int N, int H, int W, int Cpad, int Ko, int R, int S, int stride, int pad);
-size_t cxrk_bn_bwd_reduce_ws_bytes(long rows, int C);
-int cxrk_bn_bwd_reduce(const float* dy, const float* y, const float* sub, const float* beta, long rows, int C,
-                       float* sumdy, float* sumdyy, float* ws, size_t ws_bytes, hipStream_t stream);
 int cxrk_conv_bn_act_bwd_params(const float* x, const float* dy, const float* w, const float* scale, const float* rstd,
-                                const float* rmean, const float* sumdy, const float* gamma, const float* sumdyy,
-                                float* dw, float* dgamma, float* dbeta,
+                                const float* rmean, const float* sumdy, float* dw, float* dgamma, float* dbeta,
                                 int accumulate, int N, int H, int W, int C, int Cpad, int Ko, int R, int S, int stride,
                                 int pad, float* ws, size_t ws_bytes, hipStream_t stream);
+int cxrk_conv_bn_act_bwd_params_pl(const void* x, long xplane, const void* dy, long dyplane, const float* w, const float* scale,
+                                   const float* rstd, const float* rmean, const float* sumdy, float* dw, float* dgamma,
+                                   float* dbeta, int accumulate, int N, int H, int W, int C, int Ko, int R, int S, int stride,
+                                   int pad, float* ws, size_t ws_bytes, hipStream_t stream);
 
 /* Boundary layout transforms: torch NCHW input (model.py:141) <-> NHWC working layout. */
 int cxrk_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int Cpad, hipStream_t stream);
@@ -101,10 +128,18 @@ int cxrk_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, hipS
 int cxrk_maxpool_fwd(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, hipStream_t stream);
 int cxrk_maxpool_bwd(const float* dy, const unsigned char* idx, const float* x, float* dx, int N, int H, int W, int C,
                      int relu_mask, hipStream_t stream);
+/* planes variants: x / y / dy / pooled are planes.  The backward masks with the stem ReLU through the sign of `pooled` (the
+ * pooled value IS the winning input) and writes dx in fp32 (it feeds the stem's exact-fp32 weight gradient). */
+int cxrk_maxpool_fwd_pl(const void* x, long xplane, void* y, long yplane, unsigned char* idx, int N, int H, int W, int C,
+                        hipStream_t stream);
+int cxrk_maxpool_bwd_pl(const void* dy, long dyplane, const unsigned char* idx, const void* pooled, float* dx, int N, int H,
+                        int W, int C, hipStream_t stream);
 
 /* spatial_mean — torch.mean(projected_patch_embeddings, dim=(2,3)) (model.py:145). x[N][P][C] -> y[N][C]. */
 int cxrk_spatial_mean_fwd(const float* x, float* y, int N, int P, int C, hipStream_t stream);
 int cxrk_spatial_mean_bwd(const float* dy, float* dx, int N, int P, int C, hipStream_t stream);
+/* dx (planes [N][P][C]) = dy[n][c] / P + add[n][p][c] (add optional, fp32) */
+int cxrk_spatial_mean_bwd_pl(const float* dy, const float* add, void* dx, long dxplane, int N, int P, int C, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * CXR-BERT pieces (HF BertForMaskedLM under modelling_cxrbert.py:87-99; config configuration_cxrbert.py:11-22).
@@ -114,20 +149,24 @@ int cxrk_spatial_mean_bwd(const float* dy, float* dx, int N, int P, int C, hipSt
  * attn:        ctx = softmax(Q K^T / sqrt(d) + keymask) V per (sequence, head); qkv is the fused [T][3*nH*d]
  *              projection output; probs [B][nH][L][L] saved for bwd.  L <= 64, d <= 64 (multiple of 4).
  * embed_bwd:   dword[ids[t]] += dx[t]   (fp32 atomics)
+ * Outputs declared `void* y, long yplane`: yplane = 0 -> fp32 tensor; yplane > 0 -> planes (bf16 hi at y, lo at y + yplane
+ * elements), the format the following GEMM consumes in split-bf16 mode.
  */
 int cxrk_embed_ln_fwd(const long* ids, const float* word, const float* pos, const float* type, const float* gamma,
-                      const float* beta, float eps, long T, int L, int H, float* y, float* xhat, float* rstd,
+                      const float* beta, float eps, long T, int L, int H, void* y, long yplane, float* xhat, float* rstd,
                       hipStream_t stream);
 int cxrk_residual_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps, long rows,
-                         int H, float* y, float* xhat, float* rstd, hipStream_t stream);
+                         int H, void* y, long yplane, float* xhat, float* rstd, hipStream_t stream);
 size_t cxrk_residual_ln_bwd_ws_bytes(long rows, int H);
 int cxrk_residual_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, long rows, int H,
-                         const float* dx_add, float* dx, float* dgamma, float* dbeta, int accumulate, float* ws,
+                         const float* dx_add, void* dx, long dxplane, float* dgamma, float* dbeta, int accumulate, float* ws,
                          size_t ws_bytes, hipStream_t stream);
-int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, int nH, int dH, float* ctx, float* probs,
+/* dst[r*ld + c] += src[r][c] for a planes tensor src [rows][cols] (the CLS-row gradient added into a [N, L, H] fp32 gradient) */
+int cxrk_planes_add_rows(const void* src, long plane, long rows, int cols, float* dst, long ld, hipStream_t stream);
+int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, int nH, int dH, void* ctx, long ctxplane, float* probs,
                   hipStream_t stream);
-int cxrk_attn_bwd(const float* qkv, const float* probs, const float* dctx, int B, int L, int nH, int dH, float* dqkv,
-                  hipStream_t stream);
+int cxrk_attn_bwd(const float* qkv, const float* probs, const float* dctx, int B, int L, int nH, int dH, void* dqkv,
+                  long dqkvplane, hipStream_t stream);
 int cxrk_embed_bwd(const long* ids, const float* dx, long T, int H, float* dword, hipStream_t stream);
 /* dx = dy * gelu'(pre): the erf-GELU between dense_to_hidden and LayerNorm of BertProjectionHead (modelling_cxrbert.py:45-46). */
 int cxrk_gelu_bwd(const float* dy, const float* pre, long n, float* dx, hipStream_t stream);
@@ -187,6 +226,9 @@ int cxrk_weight_reset(float* pnew, const float* pold, long n, float threshold, u
  *     with fp32 accumulation (~2^-16 relative per product; inputs, outputs and all other kernels stay fp32). */
 int cxrk_set_precision(int mode);
 int cxrk_get_precision(void);
+/* Policy of the 256x256 LDS-DMA kernel (planes operands): 0 never, 1 where it pays (default; CXRK_WIDE), 2 every planes launch
+ * (test coverage of small / ragged shapes).  Returns the previous mode. */
+int cxrk_set_wide_mode(int mode);
 
 /* Library identification: returns a static string "cxrk <version> gfx950". */
 const char* cxrk_version(void);

@@ -19,29 +19,38 @@ P, I, L, F, Z = c_void_p, c_int, c_long, c_float, c_size_t
 SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_gemm_splitk_ws_bytes": (Z, [I, I, I]),
     "cxrk_gemm_f32": (I, [I, I, I, I, I, P, L, P, L, P, L, P, P, L, P, L, I, P, L, I, F, I, I, P, Z, P]),
+    "cxrk_gemm_pl": (I, [I, I, I, I, I, P, L, L, P, L, L, P, P, L, L, P, P, P, L, L, P, L, I, P, L, P, L, P, L, I, F, I, I, P, Z, P]),
+    "cxrk_split_planes": (I, [P, L, P, L, P]),
+    "cxrk_merge_planes": (I, [P, L, L, P, P]),
+    "cxrk_colsum_pl": (I, [P, L, L, L, I, P, F, I, P, Z, P]),
     "cxrk_colsum_ws_bytes": (Z, [L, I]),
     "cxrk_colsum": (I, [P, L, L, I, P, F, I, P, Z, P]),
     "cxrk_bn_fold": (I, [P, P, P, P, P, F, I, I, I, I, P, P, P, P, P]),
     "cxrk_conv_bn_act_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
-    "cxrk_conv_bn_act_bwd_data": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
-    "cxrk_conv_bwd_data_bnsum_ws_bytes": (Z, [I, I, I, I, I]),
-    "cxrk_conv_bn_act_bwd_data_bnsum": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P, P, Z, P]),
+    "cxrk_bn_fold_pl": (I, [P, P, P, P, P, F, I, I, I, I, P, L, P, P, P, P]),
+    "cxrk_conv_bn_act_fwd_pl": (I, [P, L, P, L, I, P, P, L, P, L, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "cxrk_conv_bwd_data_colsum_ws_bytes": (Z, [I, I, I, I, I]),
+    "cxrk_conv_bn_act_bwd_data": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, Z, P]),
+    "cxrk_conv_bn_act_bwd_data_pl": (I, [P, L, P, L, P, L, P, P, L, I, I, I, I, I, I, I, I, I, P, P, Z, P]),
     "cxrk_conv_wgrad_ws_bytes": (Z, [I, I, I, I, I, I, I, I, I]),
-    "cxrk_bn_bwd_reduce_ws_bytes": (Z, [L, I]),
-    "cxrk_bn_bwd_reduce": (I, [P, P, P, P, L, I, P, P, P, Z, P]),
-    "cxrk_conv_bn_act_bwd_params": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, Z, P]),
+    "cxrk_conv_bn_act_bwd_params": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, Z, P]),
+    "cxrk_conv_bn_act_bwd_params_pl": (I, [P, L, P, L, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, Z, P]),
     "cxrk_nchw_to_nhwc": (I, [P, P, I, I, I, I, I, P]),
     "cxrk_nhwc_to_nchw": (I, [P, P, I, I, I, I, P]),
     "cxrk_maxpool_fwd": (I, [P, P, P, I, I, I, I, P]),
     "cxrk_maxpool_bwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "cxrk_maxpool_fwd_pl": (I, [P, L, P, L, P, I, I, I, I, P]),
+    "cxrk_maxpool_bwd_pl": (I, [P, L, P, P, P, I, I, I, I, P]),
     "cxrk_spatial_mean_fwd": (I, [P, P, I, I, I, P]),
     "cxrk_spatial_mean_bwd": (I, [P, P, I, I, I, P]),
-    "cxrk_embed_ln_fwd": (I, [P, P, P, P, P, P, F, L, I, I, P, P, P, P]),
-    "cxrk_residual_ln_fwd": (I, [P, P, P, P, F, L, I, P, P, P, P]),
+    "cxrk_spatial_mean_bwd_pl": (I, [P, P, P, L, I, I, I, P]),
+    "cxrk_embed_ln_fwd": (I, [P, P, P, P, P, P, F, L, I, I, P, L, P, P, P]),
+    "cxrk_residual_ln_fwd": (I, [P, P, P, P, F, L, I, P, L, P, P, P]),
     "cxrk_residual_ln_bwd_ws_bytes": (Z, [L, I]),
-    "cxrk_residual_ln_bwd": (I, [P, P, P, P, L, I, P, P, P, P, I, P, Z, P]),
-    "cxrk_attn_fwd": (I, [P, P, I, I, I, I, P, P, P]),
-    "cxrk_attn_bwd": (I, [P, P, P, I, I, I, I, P, P]),
+    "cxrk_residual_ln_bwd": (I, [P, P, P, P, L, I, P, P, L, P, P, I, P, Z, P]),
+    "cxrk_planes_add_rows": (I, [P, L, L, I, P, L, P]),
+    "cxrk_attn_fwd": (I, [P, P, I, I, I, I, P, L, P, P]),
+    "cxrk_attn_bwd": (I, [P, P, P, I, I, I, I, P, L, P]),
     "cxrk_embed_bwd": (I, [P, P, L, I, P, P]),
     "cxrk_gelu_bwd": (I, [P, P, L, P, P]),
     "cxrk_l2norm_fwd": (I, [P, L, I, F, P, P, P]),
@@ -61,10 +70,11 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_sgd": (I, [P, P, L, F, F, F, P]),
     "cxrk_weight_reset_ws_bytes": (Z, []),
     "cxrk_weight_reset": (I, [P, P, L, F, P, P, Z, P]),
-    "cxrk_gemm_wgrad_splitk": (I, [I, I, I]),
+    "cxrk_gemm_wgrad_splitk": (I, [I, I, I, I]),
     "cxrk_gemm_wide_tile": (I, [I, I, L, I, I]),
     "cxrk_set_precision": (I, [I]),
     "cxrk_get_precision": (I, []),
+    "cxrk_set_wide_mode": (I, [I]),
     "cxrk_version": (c_char_p, []),
 }
 

@@ -60,6 +60,77 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   if (rstd_out && lane == 0) rstd_out[row] = rs;
 }
 
+// H % 8 == 0: a lane owns 8 consecutive columns (lane + 64*i)*8.. -> 16-byte accesses; y is written as fp32 or as split-bf16
+// planes (yp: hi plane, lo plane yplane elements behind), the format the next GEMM consumes in split-bf16 mode.
+constexpr int LN_MAXV8 = LN_MAXV / 8;
+template <bool EMBED>
+__global__ __launch_bounds__(256) void ln_fwd_vec8_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                          const long* __restrict__ ids, const float* __restrict__ word,
+                                                          const float* __restrict__ pos, const float* __restrict__ type,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, long rows, int H, int L, float* __restrict__ y,
+                                                          unsigned short* __restrict__ yp, long yplane,
+                                                          float* __restrict__ xhat, float* __restrict__ rstd_out) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int H8 = H / 8;
+  float v[LN_MAXV8][8];
+  float s = 0.f;
+  const float* xr = EMBED ? word + ids[row] * H : x + row * H;
+  const float* rr = EMBED ? pos + (row % L) * H : (res ? res + row * H : nullptr);
+  auto ld8 = [](const float* p, float (&o)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  };
+#pragma unroll
+  for (int i = 0; i < LN_MAXV8; ++i) {
+    const int c8 = lane + i * 64;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[i][q] = 0.f;
+    if (c8 < H8) {
+      ld8(xr + c8 * 8, v[i]);
+      if (rr) { float t[8]; ld8(rr + c8 * 8, t);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[i][q] += t[q]; }
+      if (EMBED) { float t[8]; ld8(type + c8 * 8, t);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[i][q] += t[q]; }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += v[i][q];
+    }
+  }
+  const float mean = wave_sum(s) / (float)H;
+  float qq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV8; ++i) {
+    const int c8 = lane + i * 64;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const float d = c8 < H8 ? v[i][q] - mean : 0.f; v[i][q] = d; qq += d * d; }
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(qq) / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV8; ++i) {
+    const int c8 = lane + i * 64;
+    if (c8 < H8) {
+      float g[8], b[8], o[8];
+      ld8(gamma + c8 * 8, g); ld8(beta + c8 * 8, b);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { v[i][q] *= rs; o[q] = v[i][q] * g[q] + b[q]; }
+      if (xhat) {
+        *reinterpret_cast<float4*>(xhat + row * H + c8 * 8) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+        *reinterpret_cast<float4*>(xhat + row * H + c8 * 8 + 4) = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
+      }
+      if (yp) planes_store8(yp, yplane, row * H + c8 * 8, o);
+      else {
+        *reinterpret_cast<float4*>(y + row * H + c8 * 8) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(y + row * H + c8 * 8 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      }
+    }
+  }
+  if (rstd_out && lane == 0) rstd_out[row] = rs;
+}
+
 // dx = rstd * (g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma; block partial sums of dgamma/dbeta.
 // Each block handles `rows_per` rows; 4 waves take rows round-robin; partials [nblk][2][H].
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
@@ -110,6 +181,7 @@ constexpr int LN_MAXV4 = LN_MAXV / 4;
 __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                          long rows, int H, int rows_per, float* __restrict__ dx,
+                                                         unsigned short* __restrict__ dxp, long dxplane,
                                                          const float* __restrict__ dx_add, float* __restrict__ part) {
   __shared__ float sh[2][4][64 * LN_MAXV];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -148,7 +220,8 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* __restrict
         float4 o = make_float4(rs * (g[i].x - s1 - xh[i].x * s2), rs * (g[i].y - s1 - xh[i].y * s2),
                                rs * (g[i].z - s1 - xh[i].z * s2), rs * (g[i].w - s1 - xh[i].w * s2));
         if (dx_add) { const float4 a = *reinterpret_cast<const float4*>(dx_add + row * H + c4 * 4); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
-        *reinterpret_cast<float4*>(dx + row * H + c4 * 4) = o;
+        if (dxp) { const float ov[4] = {o.x, o.y, o.z, o.w}; planes_store4(dxp, dxplane, row * H + c4 * 4, ov); }
+        else *reinterpret_cast<float4*>(dx + row * H + c4 * 4) = o;
       }
     }
   }
@@ -219,6 +292,7 @@ __device__ __forceinline__ void dot2x2(const float* X, const float* Y, int ALD, 
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const long* __restrict__ mask, int L,
                                                        int nH, int dH, float scale, float* __restrict__ ctx,
+                                                       unsigned short* __restrict__ ctxp, long ctxplane,
                                                        float* __restrict__ probs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int ALD = dH + 4;   // 16-byte aligned rows
@@ -270,7 +344,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  float* out = ctx + (long)b * L * (nH * dH) + hd * dH;
+  const long obase = (long)b * L * (nH * dH) + hd * dH;
+  float* out = ctx + obase;
   for (int blk = threadIdx.x; blk < nb * d4; blk += 256) {
     const int i0 = 2 * (blk / d4), dq = blk % d4;
     const int i1 = min(i0 + 1, L - 1);
@@ -279,15 +354,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
       const float4 v = *reinterpret_cast<const float4*>(Vs + j * ALD + dq * 4);
       fma4(a0, Ps[i0 * LP + j], v); fma4(a1, Ps[i1 * LP + j], v);
     }
-    *reinterpret_cast<float4*>(out + (long)i0 * (nH * dH) + dq * 4) = a0;
-    if (i0 + 1 < L) *reinterpret_cast<float4*>(out + (long)i1 * (nH * dH) + dq * 4) = a1;
+    if (ctxp) {
+      const float v0[4] = {a0.x, a0.y, a0.z, a0.w}, v1[4] = {a1.x, a1.y, a1.z, a1.w};
+      planes_store4(ctxp, ctxplane, obase + (long)i0 * (nH * dH) + dq * 4, v0);
+      if (i0 + 1 < L) planes_store4(ctxp, ctxplane, obase + (long)i1 * (nH * dH) + dq * 4, v1);
+    } else {
+      *reinterpret_cast<float4*>(out + (long)i0 * (nH * dH) + dq * 4) = a0;
+      if (i0 + 1 < L) *reinterpret_cast<float4*>(out + (long)i1 * (nH * dH) + dq * 4) = a1;
+    }
   }
 }
 
 // dV = P^T dO ; dP = dO V^T ; dS = P o (dP - rowsum(dP o P)) ; dQ = scale * dS K ; dK = scale * dS^T Q
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
                                                        const float* __restrict__ dctx, int L, int nH, int dH, float scale,
-                                                       float* __restrict__ dqkv) {
+                                                       float* __restrict__ dqkv, unsigned short* __restrict__ dqkvp, long dqkvplane) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int ALD = dH + 4;
   float* Qs = smem; float* Ks = Qs + L * ALD; float* Vs = Ks + L * ALD; float* Os = Vs + L * ALD;
@@ -328,7 +409,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  float* dq = dqkv + (long)b * L * ld + hd * dH;
+  const long qbase = (long)b * L * ld + hd * dH;
+  float* dq = dqkv + qbase;
+  auto put = [&](long off, const float4& v) {
+    if (dqkvp) { const float t[4] = {v.x, v.y, v.z, v.w}; planes_store4(dqkvp, dqkvplane, qbase + off, t); }
+    else *reinterpret_cast<float4*>(dq + off) = v;
+  };
   for (int blk = threadIdx.x; blk < nb * d4; blk += 256) {
     const int i0 = 2 * (blk / d4), c = blk % d4;
     const int i1 = min(i0 + 1, L - 1);
@@ -342,11 +428,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
       fma4(k0, Ds[j * LP + i0], qj); fma4(k1, Ds[j * LP + i1], qj);   // dK[i] = sum_j dS[j][i] Q[j]
       fma4(v0, Ps[j * LP + i0], oj); fma4(v1, Ps[j * LP + i1], oj);   // dV[i] = sum_j P[j][i] dO[j]
     }
-    float* r0 = dq + (long)i0 * ld + c * 4;
-    *reinterpret_cast<float4*>(r0) = q0; *reinterpret_cast<float4*>(r0 + nH * dH) = k0; *reinterpret_cast<float4*>(r0 + 2 * nH * dH) = v0;
+    const long o0 = (long)i0 * ld + c * 4;
+    put(o0, q0); put(o0 + nH * dH, k0); put(o0 + 2 * nH * dH, v0);
     if (i0 + 1 < L) {
-      float* r1 = dq + (long)i1 * ld + c * 4;
-      *reinterpret_cast<float4*>(r1) = q1; *reinterpret_cast<float4*>(r1 + nH * dH) = k1; *reinterpret_cast<float4*>(r1 + 2 * nH * dH) = v1;
+      const long o1 = (long)i1 * ld + c * 4;
+      put(o1, q1); put(o1 + nH * dH, k1); put(o1 + 2 * nH * dH, v1);
     }
   }
 }
@@ -359,6 +445,21 @@ __global__ void embed_bwd_kernel(const long* __restrict__ ids, const float* __re
   for (int c = threadIdx.x; c < H; c += blockDim.x) atomicAdd(dst + c, dx[t * H + c]);
 }
 
+// dst[r*ld + c] += src[r][c]  (src planes [rows][cols], cols % 8 == 0): adds a small planes tensor into strided rows of an fp32 one
+// (the CLS rows of a [N, L, H] gradient)
+__global__ void planes_add_rows_kernel(const unsigned short* __restrict__ src, long plane, long rows, int cols, float* __restrict__ dst,
+                                       long ld) {
+  const int c8n = cols / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows * c8n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / c8n; const int c = (int)(i - r * c8n) * 8;
+    float v[8]; planes_load8(src, plane, r * cols + c, v);
+    float* d = dst + r * ld + c;
+    float4 a = *reinterpret_cast<float4*>(d), b = *reinterpret_cast<float4*>(d + 4);
+    a.x += v[0]; a.y += v[1]; a.z += v[2]; a.w += v[3]; b.x += v[4]; b.y += v[5]; b.z += v[6]; b.w += v[7];
+    *reinterpret_cast<float4*>(d) = a; *reinterpret_cast<float4*>(d + 4) = b;
+  }
+}
+
 // dx = dy * gelu'(pre)
 __global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, long n, float* __restrict__ dx) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -367,6 +468,15 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __res
 
 }  // namespace
 
+extern "C" int cxrk_planes_add_rows(const void* src, long plane, long rows, int cols, float* dst, long ld, hipStream_t stream) {
+  CXRK_CHECK_ARG(src && dst && rows > 0 && cols > 0 && (cols % 8) == 0 && (plane % 8) == 0 && (ld % 4) == 0 && aligned16(src) && aligned16(dst));
+  long nb = (rows * (cols / 8) + 255) / 256; if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(planes_add_rows_kernel, dim3((unsigned)nb), dim3(256), 0, stream, static_cast<const unsigned short*>(src), plane, rows,
+                     cols, dst, ld);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+
 extern "C" int cxrk_gelu_bwd(const float* dy, const float* pre, long n, float* dx, hipStream_t stream) {
   CXRK_CHECK_ARG(dy && pre && dx && n > 0);
   hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dy, pre, n, dx);
@@ -374,21 +484,39 @@ extern "C" int cxrk_gelu_bwd(const float* dy, const float* pre, long n, float* d
   return CXRK_OK;
 }
 
+static bool ln_vec8_ok(int H, const void* a, const void* b, const void* c, const void* d, const void* e, const void* f) {
+  return (H % 8) == 0 && aligned16(a) && aligned16(b) && aligned16(c) && aligned16(d) && aligned16(e) && aligned16(f);
+}
+
 extern "C" int cxrk_embed_ln_fwd(const long* ids, const float* word, const float* pos, const float* type,
-                                 const float* gamma, const float* beta, float eps, long T, int L, int H, float* y,
+                                 const float* gamma, const float* beta, float eps, long T, int L, int H, void* y, long yplane,
                                  float* xhat, float* rstd, hipStream_t stream) {
-  CXRK_CHECK_ARG(ids && word && pos && type && gamma && beta && y && T > 0 && L > 0 && H > 0 && H <= 64 * LN_MAXV);
-  hipLaunchKernelGGL((ln_fwd_kernel<true>), dim3((unsigned)((T + 3) / 4)), dim3(256), 0, stream, nullptr, nullptr, ids, word,
-                     pos, type, gamma, beta, eps, T, H, L, y, xhat, rstd);
+  CXRK_CHECK_ARG(ids && word && pos && type && gamma && beta && y && T > 0 && L > 0 && H > 0 && H <= 64 * LN_MAXV && yplane >= 0);
+  const bool v8 = ln_vec8_ok(H, word, pos, type, gamma, beta, y) && aligned16(xhat) && (yplane % 8) == 0;
+  if (yplane > 0 && !v8) return CXRK_ERR_ARG;
+  if (v8)
+    hipLaunchKernelGGL((ln_fwd_vec8_kernel<true>), dim3((unsigned)((T + 3) / 4)), dim3(256), 0, stream, nullptr, nullptr, ids, word, pos,
+                       type, gamma, beta, eps, T, H, L, yplane ? nullptr : static_cast<float*>(y),
+                       yplane ? static_cast<unsigned short*>(y) : nullptr, yplane, xhat, rstd);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<true>), dim3((unsigned)((T + 3) / 4)), dim3(256), 0, stream, nullptr, nullptr, ids, word,
+                       pos, type, gamma, beta, eps, T, H, L, static_cast<float*>(y), xhat, rstd);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
 }
 
 extern "C" int cxrk_residual_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps,
-                                    long rows, int H, float* y, float* xhat, float* rstd, hipStream_t stream) {
-  CXRK_CHECK_ARG(x && gamma && beta && y && rows > 0 && H > 0 && H <= 64 * LN_MAXV);
-  hipLaunchKernelGGL((ln_fwd_kernel<false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, res, nullptr, nullptr,
-                     nullptr, nullptr, gamma, beta, eps, rows, H, 1, y, xhat, rstd);
+                                    long rows, int H, void* y, long yplane, float* xhat, float* rstd, hipStream_t stream) {
+  CXRK_CHECK_ARG(x && gamma && beta && y && rows > 0 && H > 0 && H <= 64 * LN_MAXV && yplane >= 0);
+  const bool v8 = ln_vec8_ok(H, x, res, gamma, beta, y, xhat) && (yplane % 8) == 0;
+  if (yplane > 0 && !v8) return CXRK_ERR_ARG;
+  if (v8)
+    hipLaunchKernelGGL((ln_fwd_vec8_kernel<false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, res, nullptr, nullptr,
+                       nullptr, nullptr, gamma, beta, eps, rows, H, 1, yplane ? nullptr : static_cast<float*>(y),
+                       yplane ? static_cast<unsigned short*>(y) : nullptr, yplane, xhat, rstd);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, res, nullptr, nullptr,
+                       nullptr, nullptr, gamma, beta, eps, rows, H, 1, static_cast<float*>(y), xhat, rstd);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
 }
@@ -402,16 +530,20 @@ static int ln_bwd_blocks(long rows) {
 extern "C" size_t cxrk_residual_ln_bwd_ws_bytes(long rows, int H) { return (size_t)ln_bwd_blocks(rows) * 2 * H * sizeof(float); }
 
 extern "C" int cxrk_residual_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, long rows,
-                                    int H, const float* dx_add, float* dx, float* dgamma, float* dbeta, int accumulate,
+                                    int H, const float* dx_add, void* dxv, long dxplane, float* dgamma, float* dbeta, int accumulate,
                                     float* ws, size_t ws_bytes, hipStream_t stream) {
-  CXRK_CHECK_ARG(dy && xhat && rstd && gamma && dx && dgamma && dbeta && rows > 0 && H > 0 && H <= 64 * LN_MAXV);
+  CXRK_CHECK_ARG(dy && xhat && rstd && gamma && dxv && dgamma && dbeta && rows > 0 && H > 0 && H <= 64 * LN_MAXV && dxplane >= 0);
+  float* dx = dxplane ? nullptr : static_cast<float*>(dxv);
+  unsigned short* dxp = dxplane ? static_cast<unsigned short*>(dxv) : nullptr;
   int nb = ln_bwd_blocks(rows);
   if (ws == nullptr || ws_bytes < (size_t)nb * 2 * H * sizeof(float)) return CXRK_ERR_WS;
   const int rows_per = (int)((rows + nb - 1) / nb);
   nb = (int)((rows + rows_per - 1) / rows_per);
-  const bool vec = (H % 4 == 0) && aligned16(dy) && aligned16(xhat) && aligned16(gamma) && aligned16(dx) && (!dx_add || aligned16(dx_add));
+  const bool vec = (H % 4 == 0) && aligned16(dy) && aligned16(xhat) && aligned16(gamma) && aligned16(dxv) && (!dx_add || aligned16(dx_add)) &&
+                   (dxplane % 4) == 0;
+  if (dxp && !vec) return CXRK_ERR_ARG;
   if (vec)
-    hipLaunchKernelGGL(ln_bwd_vec_kernel, dim3(nb), dim3(256), 0, stream, dy, xhat, rstd, gamma, rows, H, rows_per, dx, dx_add, ws);
+    hipLaunchKernelGGL(ln_bwd_vec_kernel, dim3(nb), dim3(256), 0, stream, dy, xhat, rstd, gamma, rows, H, rows_per, dx, dxp, dxplane, dx_add, ws);
   else
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, stream, dy, xhat, rstd, gamma, rows, H, rows_per, dx, dx_add, ws);
   CXRK_LAUNCH_CHECK();
@@ -420,9 +552,11 @@ extern "C" int cxrk_residual_ln_bwd(const float* dy, const float* xhat, const fl
   return CXRK_OK;
 }
 
-extern "C" int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, int nH, int dH, float* ctx, float* probs,
+extern "C" int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, int nH, int dH, void* ctxv, long ctxplane, float* probs,
                              hipStream_t stream) {
-  CXRK_CHECK_ARG(qkv && ctx && B > 0 && nH > 0 && aligned16(qkv) && aligned16(ctx));
+  CXRK_CHECK_ARG(qkv && ctxv && B > 0 && nH > 0 && aligned16(qkv) && aligned16(ctxv) && ctxplane >= 0 && (ctxplane % 4) == 0);
+  float* ctx = ctxplane ? nullptr : static_cast<float*>(ctxv);
+  unsigned short* ctxp = ctxplane ? static_cast<unsigned short*>(ctxv) : nullptr;
   if (dH > AD || dH < 4 || (dH % 4) != 0 || L > AL || L < 1) return CXRK_ERR_UNSUPPORTED;
   const int ALD = dH + 4;
   const size_t sh = (size_t)(3 * L * ALD + L * (L + 1)) * sizeof(float);
@@ -433,14 +567,17 @@ extern "C" int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, i
     attr_set = true;
   }
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * nH)), dim3(256), sh, stream, qkv, mask, L, nH, dH,
-                     1.0f / sqrtf((float)dH), ctx, probs);
+                     1.0f / sqrtf((float)dH), ctx, ctxp, ctxplane, probs);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
 }
 
 extern "C" int cxrk_attn_bwd(const float* qkv, const float* probs, const float* dctx, int B, int L, int nH, int dH,
-                             float* dqkv, hipStream_t stream) {
-  CXRK_CHECK_ARG(qkv && probs && dctx && dqkv && B > 0 && nH > 0 && aligned16(qkv) && aligned16(dctx) && aligned16(dqkv));
+                             void* dqkvv, long dqkvplane, hipStream_t stream) {
+  CXRK_CHECK_ARG(qkv && probs && dctx && dqkvv && B > 0 && nH > 0 && aligned16(qkv) && aligned16(dctx) && aligned16(dqkvv) && dqkvplane >= 0 &&
+                 (dqkvplane % 4) == 0);
+  float* dqkv = dqkvplane ? nullptr : static_cast<float*>(dqkvv);
+  unsigned short* dqkvp = dqkvplane ? static_cast<unsigned short*>(dqkvv) : nullptr;
   if (dH > AD || dH < 4 || (dH % 4) != 0 || L > AL || L < 1) return CXRK_ERR_UNSUPPORTED;
   const int ALD = dH + 4;
   const size_t sh = (size_t)(4 * L * ALD + 2 * L * (L + 1)) * sizeof(float);
@@ -451,7 +588,7 @@ extern "C" int cxrk_attn_bwd(const float* qkv, const float* probs, const float* 
     attr_set = true;
   }
   hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * nH)), dim3(256), sh, stream, qkv, probs, dctx, L, nH, dH,
-                     1.0f / sqrtf((float)dH), dqkv);
+                     1.0f / sqrtf((float)dH), dqkv, dqkvp, dqkvplane);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
 }

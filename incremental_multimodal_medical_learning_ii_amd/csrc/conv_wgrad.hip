@@ -1,0 +1,163 @@
+// ResNet-50 image-encoder kernels, weight gradient: split-K implicit GEMM over the pixels, deterministic slab reduction that also
+// produces the BatchNorm gamma / beta gradients.
+#include "conv_common.h"
+
+using namespace cxrk;
+
+namespace {
+// dW[ko][tap][c] = scale[ko] * sum_z slab_z[ko][tap][c<Cpad]  (channel un-padding), one block per (ko, part of the filter).
+// BatchNorm parameter gradients of the unit (eval-mode statistics: y = gamma*(z - mean)*rstd + beta, z = conv(x, w)):
+//   dbeta[ko] = sum dy,    dgamma[ko] = sum dy*(z - mean)*rstd = rstd * (<w[ko], dWraw[ko]> - mean * sum dy)
+// i.e. the gamma gradient comes out of the raw weight gradient this kernel is summing anyway: nothing has to be read from
+// the activations, and gamma is never divided by (gamma = 0 or denormal is as good as any other value).  Conditioning was
+// measured on the real ResNet-50 (scripts/exp_dgamma.py): against the direct sum it differs by < 1e-6 of the tensor maximum.
+// Each block adds its part of <w, dWraw> into dotpart[ko][blockIdx.y]; bn_param_grad_kernel finishes.
+// Slab sum: a block covers QPB = 256 >> sg_log2 float4 outputs of filter ko; its threads are split into SG = 1 << sg_log2
+// groups that walk the slabs SG apart (4 loads in flight each), and the SG partial sums are added in group order through
+// LDS (deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_bn_kernel(const float* __restrict__ slabs, int nslab, long slab_stride,
+                                                              int taps, int C, int Cpad, const float* __restrict__ w,
+                                                              const float* __restrict__ scale, float* __restrict__ dw,
+                                                              float* __restrict__ dotpart, int accumulate, int sg_log2) {
+  __shared__ float sh[16];
+  __shared__ float4 red[256];
+  const int ko = blockIdx.x;
+  const int n = taps * Cpad;
+  const float sc = scale ? scale[ko] : 1.f;
+  const int SG = 1 << sg_log2, QPB = 256 >> sg_log2;
+  const int ql = threadIdx.x & (QPB - 1), grp = threadIdx.x >> (8 - sg_log2);
+  const int i4 = (blockIdx.y * QPB + ql) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i4 < n) {  // Cpad % 4 == 0 -> the 4 elements share a tap
+    const float* src = slabs + (long)ko * n + i4;
+    int z = grp;
+    for (; z + 3 * SG < nslab; z += 4 * SG) {
+      const float4 t0 = *reinterpret_cast<const float4*>(src + (long)z * slab_stride);
+      const float4 t1 = *reinterpret_cast<const float4*>(src + (long)(z + SG) * slab_stride);
+      const float4 t2 = *reinterpret_cast<const float4*>(src + (long)(z + 2 * SG) * slab_stride);
+      const float4 t3 = *reinterpret_cast<const float4*>(src + (long)(z + 3 * SG) * slab_stride);
+      s.x += (t0.x + t1.x) + (t2.x + t3.x); s.y += (t0.y + t1.y) + (t2.y + t3.y);
+      s.z += (t0.z + t1.z) + (t2.z + t3.z); s.w += (t0.w + t1.w) + (t2.w + t3.w);
+    }
+    for (; z < nslab; z += SG) {
+      const float4 t = *reinterpret_cast<const float4*>(src + (long)z * slab_stride);
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+  }
+  if (SG > 1) {
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (grp == 0) {
+      for (int g2 = 1; g2 < SG; ++g2) { const float4 t = red[g2 * QPB + ql]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+    }
+  }
+  float dot = 0.f;
+  if (i4 < n && grp == 0) {
+    const int tap = i4 / Cpad, c = i4 - tap * Cpad;
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (c + q < C) {
+        const long o = ((long)ko * taps + tap) * C + c + q;
+        if (dotpart) dot += w[o] * sv[q];
+        dw[o] = accumulate ? dw[o] + sc * sv[q] : sc * sv[q];
+      }
+    }
+  }
+  if (dotpart) {
+    dot = block_sum(dot, sh);
+    if (threadIdx.x == 0) dotpart[(long)ko * gridDim.y + blockIdx.y] = dot;
+  }
+}
+__global__ void bn_param_grad_kernel(const float* __restrict__ dotpart, int nparts, const float* __restrict__ rstd,
+                                     const float* __restrict__ rmean, const float* __restrict__ sumdy, int Ko,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+  const int ko = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ko >= Ko) return;
+  float dot = 0.f;
+  for (int p = 0; p < nparts; ++p) dot += dotpart[(long)ko * nparts + p];
+  const float g = rstd[ko] * (dot - rmean[ko] * sumdy[ko]);
+  dgamma[ko] = accumulate ? dgamma[ko] + g : g;
+  dbeta[ko] = accumulate ? dbeta[ko] + sumdy[ko] : sumdy[ko];
+}
+
+}  // namespace
+
+// ---- weight gradient (+ BatchNorm parameter gradients) -----------------------------------------------------------------
+static int wgrad_splitk(int Ko, int Ncols, long Kred, bool planes) { return wgrad_splitk_policy(Ko, Ncols, (int)Kred, planes); }
+static int wgrad_dot_parts(int Nc) { return ceil_div(Nc, 64); }   // upper bound of the reduction grid's y extent
+
+extern "C" size_t cxrk_conv_wgrad_ws_bytes(int N, int H, int W, int C, int Ko, int R, int S, int stride, int pad) {
+  const ConvGeom g = make_geom(N, H, W, C, Ko, R, S, stride, pad);
+  int sk = wgrad_splitk(Ko, R * S * C, (long)N * g.Ho * g.Wo, false);   // upper bound over both storage formats
+  const int sk2 = wgrad_splitk(Ko, R * S * C, (long)N * g.Ho * g.Wo, true);
+  if (sk2 > sk) sk = sk2;
+  return ((size_t)sk * (size_t)Ko * (size_t)(R * S * C) + (size_t)Ko * wgrad_dot_parts(R * S * C)) * sizeof(float);
+}
+
+// dW (+ BN parameter gradients).  x: conv input [N,H,W,Cpad]; dy: gradient w.r.t. the BN output, already ReLU-masked.
+// w: raw (unscaled) filter [Ko][R][S][C]; sumdy[ko] = sum of dy over (n,ho,wo).  C may be < Cpad (stem).
+template <class FMT>
+static int conv_bwd_params_impl(const typename FMT::T* x, long xplane, const typename FMT::T* dy, long dyplane, const float* w,
+                                const float* scale, const float* rstd, const float* rmean, const float* sumdy, float* dw,
+                                float* dgamma, float* dbeta, int accumulate, int N, int H, int W, int C, int Cpad, int Ko, int R,
+                                int S, int stride, int pad, float* ws, size_t ws_bytes, hipStream_t stream) {
+  CXRK_CHECK_ARG(x && dy && dw && N > 0 && Cpad % FMT::EPL == 0 && Ko % FMT::EPL == 0 && aligned16(x) && aligned16(dy));
+  CXRK_CHECK_ARG(!(dgamma && !(w && rstd && rmean && sumdy && dbeta)));
+  const ConvGeom g = make_geom(N, H, W, Cpad, Ko, R, S, stride, pad);
+  const long Kl = (long)N * g.Ho * g.Wo;
+  CXRK_CHECK_ARG(Kl < (1L << 31));
+  const int Kred = (int)Kl, Nc = R * S * Cpad;
+  if ((long)H * W * Cpad * 4 * 3 >= (1L << 31)) return CXRK_ERR_UNSUPPORTED;  // a K-tile of 32 pixels spans <= 3 images
+  int sk = wgrad_splitk(Ko, Nc, Kl, FMT::PLANES);
+  const size_t slab_floats = (size_t)sk * Ko * Nc;
+  if (ws == nullptr || ws_bytes < (slab_floats + (size_t)Ko * wgrad_dot_parts(Nc)) * sizeof(float)) return CXRK_ERR_WS;
+  EpiParams ep{};
+  ep.C = ws; ep.ldc = Nc; ep.alpha = 1.f; ep.slab_stride = (long)Ko * Nc;
+  int rc;
+  const bool exact = Cpad <= 4;   // the stem: an all-positive input makes its weight gradient a cancelling sum
+  if (use_wide256(Ko, Nc, Kred, sk, FMT::PLANES)) {
+    if constexpr (FMT::PLANES) {
+      DmaDenseMC::P pa{dy, (long)Ko, Ko, Kred, dyplane}; DmaConvIm2colMC::P pb{x, g, Nc, Kred, xplane};
+      rc = launch_gemm_pw<DmaDenseMC, DmaConvIm2colMC>(pa, pb, ep, Ko, Nc, Kred, sk, stream);
+    } else return CXRK_ERR_UNSUPPORTED;
+  } else if (Ko <= 64) {
+    typename DenseMC<64, FMT>::P pa{dy, (long)Ko, Ko, Kred, dyplane}; typename ConvIm2colMC<256, FMT>::P pb{x, g, Nc, Kred, xplane};
+    rc = launch_gemm<DenseMC<64, FMT>, ConvIm2colMC<256, FMT>, 1, 4>(pa, pb, ep, Ko, Nc, Kred, sk, stream, exact);
+  } else {
+    typename DenseMC<128, FMT>::P pa{dy, (long)Ko, Ko, Kred, dyplane}; typename ConvIm2colMC<128, FMT>::P pb{x, g, Nc, Kred, xplane};
+    rc = launch_gemm<DenseMC<128, FMT>, ConvIm2colMC<128, FMT>, 2, 2>(pa, pb, ep, Ko, Nc, Kred, sk, stream, exact);
+  }
+  if (rc < 0) return rc;
+  const int sg_log2 = rc >= 64 ? 4 : (rc >= 8 ? 2 : 0);  // slab groups per block: 16 / 4 / 1
+  const int ny = ceil_div(Nc, 4 * (256 >> sg_log2));
+  float* dotpart = dgamma ? ws + slab_floats : nullptr;
+  hipLaunchKernelGGL(wgrad_reduce_bn_kernel, dim3(Ko, ny), dim3(256), 0, stream, ws, rc, (long)Ko * Nc, R * S, C, Cpad, w, scale, dw,
+                     dotpart, accumulate, sg_log2);
+  CXRK_LAUNCH_CHECK();
+  if (dgamma) {
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(ceil_div(Ko, 256)), dim3(256), 0, stream, dotpart, ny, rstd, rmean, sumdy, Ko, dgamma,
+                       dbeta, accumulate);
+    CXRK_LAUNCH_CHECK();
+  }
+  return CXRK_OK;
+}
+
+extern "C" int cxrk_conv_bn_act_bwd_params(const float* x, const float* dy, const float* w, const float* scale,
+                                           const float* rstd, const float* rmean, const float* sumdy, float* dw,
+                                           float* dgamma, float* dbeta, int accumulate, int N, int H, int W, int C,
+                                           int Cpad, int Ko, int R, int S, int stride, int pad, float* ws, size_t ws_bytes,
+                                           hipStream_t stream) {
+  return conv_bwd_params_impl<F32>(x, 0, dy, 0, w, scale, rstd, rmean, sumdy, dw, dgamma, dbeta, accumulate, N, H, W, C, Cpad, Ko, R, S,
+                                   stride, pad, ws, ws_bytes, stream);
+}
+extern "C" int cxrk_conv_bn_act_bwd_params_pl(const void* x, long xplane, const void* dy, long dyplane, const float* w,
+                                              const float* scale, const float* rstd, const float* rmean, const float* sumdy,
+                                              float* dw, float* dgamma, float* dbeta, int accumulate, int N, int H, int W, int C,
+                                              int Ko, int R, int S, int stride, int pad, float* ws, size_t ws_bytes,
+                                              hipStream_t stream) {
+  return conv_bwd_params_impl<PL>(static_cast<const unsigned short*>(x), xplane, static_cast<const unsigned short*>(dy), dyplane, w, scale,
+                                  rstd, rmean, sumdy, dw, dgamma, dbeta, accumulate, N, H, W, C, C, Ko, R, S, stride, pad, ws, ws_bytes,
+                                  stream);
+}
+

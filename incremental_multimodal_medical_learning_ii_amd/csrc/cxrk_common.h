@@ -74,6 +74,63 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// ---- split-bf16 ("planes") storage -----------------------------------------------------------------------------------
+// x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi).
+// 5 vector instructions per pair: v_cvt_pk_bf16_f32 (hi, round-to-nearest-even), shift / mask back to f32, one packed
+// subtract, v_cvt_pk_bf16_f32 (lo).  The first conversion is inline asm so that the compiler keeps the packed result
+// instead of converting each element a second time on its own.
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  unsigned hp;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hp) : "v"(x0), "v"(x1));
+  const f32x2 x = {x0, x1};
+  const f32x2 hf = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xffff0000u)};
+  const f32x2 l = x - hf;
+  const bf16x2 lb = {(__bf16)l[0], (__bf16)l[1]};
+  hi = hp; lo = __builtin_bit_cast(unsigned, lb);
+}
+// ---- planes helpers (device side of the split-bf16 storage format) -----------------------------------------------
+// 8 consecutive elements: hi plane word pairs h.x..h.w (2 bf16 each), same for lo; value = hi + lo.
+__device__ __forceinline__ void planes_unpack8(const uint4& h, const uint4& l, float (&v)[8]) {
+  const unsigned hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[2 * q] = __builtin_bit_cast(float, hw[q] << 16) + __builtin_bit_cast(float, lw[q] << 16);
+    v[2 * q + 1] = __builtin_bit_cast(float, hw[q] & 0xffff0000u) + __builtin_bit_cast(float, lw[q] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void planes_pack8(const float (&v)[8], uint4& h, uint4& l) {
+  split2(v[0], v[1], h.x, l.x); split2(v[2], v[3], h.y, l.y); split2(v[4], v[5], h.z, l.z); split2(v[6], v[7], h.w, l.w);
+}
+__device__ __forceinline__ void planes_load8(const unsigned short* hi, long plane, long off, float (&v)[8]) {
+  const uint4 h = *reinterpret_cast<const uint4*>(hi + off);
+  const uint4 l = *reinterpret_cast<const uint4*>(hi + plane + off);
+  planes_unpack8(h, l, v);
+}
+__device__ __forceinline__ void planes_store8(unsigned short* hi, long plane, long off, const float (&v)[8], bool nt = false) {
+  uint4 h, l;
+  planes_pack8(v, h, l);
+  if (nt) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 hv = {h.x, h.y, h.z, h.w}, lv = {l.x, l.y, l.z, l.w};
+    __builtin_nontemporal_store(hv, reinterpret_cast<u32x4*>(hi + off));
+    __builtin_nontemporal_store(lv, reinterpret_cast<u32x4*>(hi + plane + off));
+  } else {
+    *reinterpret_cast<uint4*>(hi + off) = h;
+    *reinterpret_cast<uint4*>(hi + plane + off) = l;
+  }
+}
+
+// 4 consecutive elements (8 bytes of each plane)
+__device__ __forceinline__ void planes_store4(unsigned short* hi, long plane, long off, const float (&v)[4]) {
+  uint2 h, l;
+  split2(v[0], v[1], h.x, l.x); split2(v[2], v[3], h.y, l.y);
+  *reinterpret_cast<uint2*>(hi + off) = h;
+  *reinterpret_cast<uint2*>(hi + plane + off) = l;
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 

@@ -33,7 +33,7 @@ struct EpiParams {
   const float* bias;             // per column n, or null
   const float* R; long ldr;      // residual added before the activation, or null
   const float* aux; long ldaux;  // auxmode 1: v *= (aux > 0); auxmode 2: v *= gelu'(aux)
-  int auxmode;
+  int auxmode;                   // auxmode 3 (planes epilogue): v *= bit of maskin
   float* C2; long ldc2;          // optional copy of the pre-activation value
   int act;                       // 0 none, 1 relu, 2 gelu(erf)
   float alpha;                   // scales the accumulator
@@ -42,10 +42,20 @@ struct EpiParams {
   int rm_on, rm_Hs, rm_Ws, rm_H, rm_W, rm_ph, rm_pw;
   int vec;  // set by launch_gemm: every pointer / leading dimension allows 16-byte row accesses
   int nt;   // set by launch_gemm: store C non-temporally (large outputs)
-  // optional fused BatchNorm-backward reductions over the rows of this launch (needs auxmode 1, vec): with v the stored
-  // value and y = aux,   S0[c] = sum v,   S1[c] = sum v*(y - sub - beta[c]),   S2[c] = sum v*(sub - beta2[c]).
-  // Per-wave partials go to bn_part[(mt*WM + wm)][3][N]; a second kernel adds them up (deterministic).
-  float* bn_part; const float* bn_sub; long bn_ldsub; const float* bn_beta; const float* bn_beta2;
+  // optional fused column sums of the stored values over the rows of this launch (the BatchNorm beta gradient of the unit
+  // whose output gradient this launch produces): per-wave partials go to colsum_part[(mt*WM + wm)][N]; a second kernel adds
+  // them up (deterministic).  Needs vec.
+  float* colsum_part;
+  // ---- "planes" operands (split-bf16 storage, see gemm_loaders.h): any of these selects the 8-columns-per-lane epilogue
+  unsigned short* Cp; long cplane;          // output as bf16 hi/lo planes (hi at Cp, lo at Cp + cplane; row stride ldc) instead of C
+  const unsigned short* Rp; long rplane;    // residual given as planes (row stride ldr) instead of R
+  const unsigned char* maskin; long ldmaskin;   // auxmode 3: ReLU decision bits, byte [row][col / 8], bit col % 8
+  unsigned char* maskout; long ldmaskout;       // act 1: also store the ReLU decision bits of this launch's output
+  int pl;   // set by launch_gemm: a planes / bit-mask operand is present
+  int fast; // set by launch_gemm: every operand allows the 8-columns-per-lane epilogue (gemm_epilogue.h)
+  int kind; // set by launch_gemm: index of the compiled-in feature set (EPI_KINDS), or -1 = generic
+  // diagnostics only (scripts/tune_pw.hip): per-block s_memtime stamps [block][8]; null in the library
+  unsigned long long* stamps;
 };
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -55,21 +65,7 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 // a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 MFMA (fp32 accumulate), dropping only a_lo*b_lo (2^-16 relative).
 constexpr int LDH = BK + 8;  // LDS row stride of a bf16 operand tile, in halfwords (80 B: conflict-free ds_read_b128)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-// 5 vector instructions per pair: v_cvt_pk_bf16_f32 (hi, round-to-nearest-even), shift / mask back to f32, one packed
-// subtract, v_cvt_pk_bf16_f32 (lo).  The first conversion is inline asm so that the compiler keeps the packed result
-// instead of converting each element a second time on its own.
-__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  unsigned hp;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hp) : "v"(x0), "v"(x1));
-  const f32x2 x = {x0, x1};
-  const f32x2 hf = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xffff0000u)};
-  const f32x2 l = x - hf;
-  const bf16x2 lb = {(__bf16)l[0], (__bf16)l[1]};
-  hi = hp; lo = __builtin_bit_cast(unsigned, lb);
-}
 __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
   split2(v.x, v.y, hi.x, lo.x);
   split2(v.z, v.w, hi.y, lo.y);
@@ -118,22 +114,25 @@ __device__ __forceinline__ bf16x8 frag_mc(const unsigned short* plane, int row0,
 namespace cxrk {
 
 // ---------------------------------------------------------------------------------------------------------------
-// Kernel
+// Epilogues shared by the fp32 and the split-bf16 mainloops (both MFMA shapes have the same 32x32 C/D map).
+// C/D map of the 32x32 MFMAs: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), i.e. a lane owns ONE column — stored
+// straight from the accumulators that is 64 dword stores per lane in 128-B pieces.  Instead each wave transposes its 64x64
+// sub-tile through the (now free) operand LDS in two 32-row passes and leaves with whole 16-byte pieces of a row per lane;
+// the residual / mask / GELU' side inputs are read the same way.  This is what the HBM-bound shapes (1x1 convolutions with
+// K = 64) pay for.
+// `st` = this wave's 32x64-float staging area in LDS (no other wave touches it); `part` = index of this 64-row slab among the
+// fused column-sum partials (row0 / 64 over the padded row range).
 // ---------------------------------------------------------------------------------------------------------------
-// ---------------------------------------------------------------------------------------------------------------
-// Epilogue shared by the fp32 and the split-bf16 mainloops (both MFMA shapes have the same 32x32 C/D map).
-// `smem` = at least 4 * 32 * 64 floats of LDS that no wave reads any more.
-// ---------------------------------------------------------------------------------------------------------------
-// One wave's 64x64 sub-tile: rows row0.., columns col0..; `st` = this wave's 32x64-float staging area in LDS;
-// `part` = index of this 64-row slab among the fused BatchNorm partial sums (row0 / 64 over the padded row range).
-__device__ __forceinline__ void gemm_epilogue64(f32x16 (&acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0,
-                                                int col0, int part, int z, int lane) {
+__device__ __forceinline__ long epi_row(const EpiParams& ep, int grow) {
+  if (!ep.rm_on) return grow;
+  const int b_ = grow % ep.rm_Ws; const int q_ = grow / ep.rm_Ws; const int a_ = q_ % ep.rm_Hs; const int n_ = q_ / ep.rm_Hs;
+  return ((long)n_ * ep.rm_H + 2 * a_ + ep.rm_ph) * ep.rm_W + 2 * b_ + ep.rm_pw;
+}
+
+// fp32 operands everywhere: a lane owns 4 consecutive columns (one float4), 16 lanes a 64-column row, 4 rows per pass.
+__device__ __forceinline__ void gemm_epilogue64_f32(f32x16 (&acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0,
+                                                    int col0, int part, int z, int lane) {
   const int r = lane & 31, h = lane >> 5;
-  // Epilogue.  C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), i.e. a
-  // lane owns ONE column — stored straight from the accumulators that is 64 dword stores per lane in 128-B pieces.
-  // Instead each wave transposes its 64x64 sub-tile through the (now free) operand LDS in two 32-row passes and
-  // leaves with 16 B per lane: 16 float4 stores per lane, 256 contiguous bytes per row, and the residual / mask /
-  // GELU' side inputs are read the same way.  This is what the HBM-bound shapes (1x1 convolutions with K = 64) pay for.
   float* C = ep.C + (long)z * ep.slab_stride;
   const int c4 = lane & 15, rq = lane >> 4;
   const int col = col0 + c4 * 4;
@@ -142,13 +141,7 @@ __device__ __forceinline__ void gemm_epilogue64(f32x16 (&acc)[2][2], const EpiPa
     if (ep.vec) bv = *reinterpret_cast<const float4*>(ep.bias + col);
     else { bv.x = ep.bias[col]; if (col + 1 < N) bv.y = ep.bias[col + 1]; if (col + 2 < N) bv.z = ep.bias[col + 2]; if (col + 3 < N) bv.w = ep.bias[col + 3]; }
   }
-  float bs[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  float bb1[4] = {0.f, 0.f, 0.f, 0.f}, bb2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (ep.bn_part && col < N) {
-    const float4 t1 = *reinterpret_cast<const float4*>(ep.bn_beta + col);
-    bb1[0] = t1.x; bb1[1] = t1.y; bb1[2] = t1.z; bb1[3] = t1.w;
-    if (ep.bn_beta2) { const float4 t2 = *reinterpret_cast<const float4*>(ep.bn_beta2 + col); bb2[0] = t2.x; bb2[1] = t2.y; bb2[2] = t2.z; bb2[3] = t2.w; }
-  }
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -161,17 +154,13 @@ __device__ __forceinline__ void gemm_epilogue64(f32x16 (&acc)[2][2], const EpiPa
 #pragma unroll
     for (int tg = 0; tg < 2; ++tg) {
       long rows[4]; bool live[4];
-      float4 pr[4], pa[4];   // residual and ReLU / GELU' source; the rarer BatchNorm term is read in place (registers)
+      float4 pr[4], pa[4];   // residual and ReLU / GELU' source
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int rl = (tg * 4 + u) * 4 + rq;
         const int grow = row0 + i * 32 + rl;
         live[u] = grow < M && col < N;
-        long row = grow;
-        if (ep.rm_on) {
-          const int b_ = grow % ep.rm_Ws; const int q_ = grow / ep.rm_Ws; const int a_ = q_ % ep.rm_Hs; const int n_ = q_ / ep.rm_Hs;
-          row = ((long)n_ * ep.rm_H + 2 * a_ + ep.rm_ph) * ep.rm_W + 2 * b_ + ep.rm_pw;
-        }
+        const long row = epi_row(ep, grow);
         rows[u] = row;
         pr[u] = pa[u] = zero4();
         if (ep.vec && live[u]) {
@@ -201,16 +190,10 @@ __device__ __forceinline__ void gemm_epilogue64(f32x16 (&acc)[2][2], const EpiPa
             const float ax[4] = {pa[u].x, pa[u].y, pa[u].z, pa[u].w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = ep.auxmode == 1 ? (ax[q] > 0.f ? v[q] : 0.f) : v[q] * gelu_erf_grad(ax[q]);
-            if (ep.bn_part) {
-              float sb[4] = {0.f, 0.f, 0.f, 0.f};
-              if (ep.bn_sub) { const float4 s4 = *reinterpret_cast<const float4*>(ep.bn_sub + row * ep.bn_ldsub + col); sb[0] = s4.x; sb[1] = s4.y; sb[2] = s4.z; sb[3] = s4.w; }
+          }
+          if (ep.colsum_part) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                bs[0][q] += v[q];
-                bs[1][q] += v[q] * (ax[q] - sb[q] - bb1[q]);
-                bs[2][q] += v[q] * (sb[q] - bb2[q]);
-              }
-            }
+            for (int q = 0; q < 4; ++q) bs[q] += v[q];
           }
           if (ep.nt) { const f32x4 o = {v[0], v[1], v[2], v[3]}; __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(C + row * ep.ldc + col)); }
           else *reinterpret_cast<float4*>(C + row * ep.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
@@ -232,22 +215,26 @@ __device__ __forceinline__ void gemm_epilogue64(f32x16 (&acc)[2][2], const EpiPa
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (ep.bn_part) {  // add the four row-quads of the wave (lanes c4, c4+16, c4+32, c4+48), lanes 0..15 write
+  if (ep.colsum_part) {  // add the four row-quads of the wave (lanes c4, c4+16, c4+32, c4+48), lanes 0..15 write
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float t = bs[k][q];
-        t += __shfl_xor(t, 16, 64);
-        t += __shfl_xor(t, 32, 64);
-        bs[k][q] = t;
-      }
-    if (rq == 0 && col < N) {
-      float* dst = ep.bn_part + ((long)part * 3) * N + col;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) *reinterpret_cast<float4*>(dst + (long)k * N) = make_float4(bs[k][0], bs[k][1], bs[k][2], bs[k][3]);
+    for (int q = 0; q < 4; ++q) {
+      float t = bs[q];
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      bs[q] = t;
     }
+    if (rq == 0 && col < N) *reinterpret_cast<float4*>(ep.colsum_part + (long)part * N + col) = make_float4(bs[0], bs[1], bs[2], bs[3]);
   }
+}
+
+}  // namespace cxrk
+#include "gemm_epilogue.h"
+namespace cxrk {
+
+__device__ __forceinline__ void gemm_epilogue64(f32x16 (&acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0,
+                                                int col0, int part, int z, int lane) {
+  if (ep.fast) epi64_dispatch<0>(ep.kind, acc, ep, st, M, N, row0, col0, part, z, lane);
+  else gemm_epilogue64_f32(acc, ep, st, M, N, row0, col0, part, z, lane);   // odd widths / unaligned fp32 operands
 }
 
 template <int WM, int WN>
@@ -326,6 +313,7 @@ __global__ __launch_bounds__(NTHREADS, CXRK_OCC) void gemm_f32_kernel(typename L
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  static_assert(!LA::FMT_PLANES && !LB::FMT_PLANES, "the exact-fp32 mainloop reads fp32 operands");
   float4 ra[LA::NV], rb[LB::NV];
   if (kbeg < kend) {
     la.load(kbeg, ra); lb.load(kbeg, rb);
@@ -416,7 +404,7 @@ __global__ __launch_bounds__(NTHREADS, (WM == 2 && WN == 2) ? 3 : 2) void gemm_x
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float4 ra[LA::NV], rb[LB::NV];
+  typename LA::V ra[LA::NV]; typename LB::V rb[LB::NV];
   if (kbeg < kend) {
     la.load(kbeg, ra); lb.load(kbeg, rb);
     la.store2(Ahi, Alo, ra); lb.store2(Bhi, Blo, rb);
@@ -461,115 +449,6 @@ __global__ __launch_bounds__(NTHREADS, (WM == 2 && WN == 2) ? 3 : 2) void gemm_x
   gemm_epilogue<WM, WN>(acc, ep, reinterpret_cast<float*>(smem16), M, N, m0, n0, mt, z, wave, lane);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// 256x256 split-bf16 mainloop: 512 threads = 8 waves as 2 (M) x 4 (N), 128x64 outputs per wave (4x2 MFMA tiles, 128
-// accumulator registers), one block per CU, two LDS buffers (2 x 80 KB = all of the CU's LDS).
-// Against the 128x128 tile every per-MFMA overhead of the loop is smaller: operand bytes through L1 and the
-// convert + LDS-store work per MFMA are halved ((BM + BN) / (BM * BN)), fragment reads drop from 8 to 6 per 12 MFMAs.
-// With one block per CU nothing else hides a phase, so the K-tile is a single software-pipelined phase: A(t+1) is
-// converted and stored beside the first half of the MFMAs of tile t and its registers are re-loaded with A(t+2) at once,
-// the same for B beside the second half; one barrier per K-tile.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int NT_WIDE = 512;
-
-template <class LA, class LB>
-__device__ __forceinline__ void x3w_mfma_block(const unsigned short* Ahi, const unsigned short* Alo, const unsigned short* Bhi,
-                                               const unsigned short* Blo, int wm, int wn, int kc, int lane,
-                                               f32x16 (&acc0)[2][2], f32x16 (&acc1)[2][2]) {
-  bf16x8 ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    if constexpr (LB::KC) {
-      bh[j] = frag_kc(Bhi, wn * 64 + j * 32, kc, lane); bl[j] = frag_kc(Blo, wn * 64 + j * 32, kc, lane);
-    } else {
-      bh[j] = frag_mc<LB::LDT>(Bhi, wn * 64 + j * 32, kc, lane); bl[j] = frag_mc<LB::LDT>(Blo, wn * 64 + j * 32, kc, lane);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if constexpr (LA::KC) {
-      ah[i] = frag_kc(Ahi, wm * 128 + i * 32, kc, lane); al[i] = frag_kc(Alo, wm * 128 + i * 32, kc, lane);
-    } else {
-      ah[i] = frag_mc<LA::LDT>(Ahi, wm * 128 + i * 32, kc, lane); al[i] = frag_mc<LA::LDT>(Alo, wm * 128 + i * 32, kc, lane);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc0[i][j], 0, 0, 0);
-      acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc0[i][j], 0, 0, 0);
-      acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc0[i][j], 0, 0, 0);
-    }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[2 + i], bh[j], acc1[i][j], 0, 0, 0);
-      acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[2 + i], bl[j], acc1[i][j], 0, 0, 0);
-      acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[2 + i], bh[j], acc1[i][j], 0, 0, 0);
-    }
-}
-
-template <class LA, class LB>
-__global__ __launch_bounds__(NT_WIDE, 1) void gemm_x3w_kernel(typename LA::P pa, typename LB::P pb, EpiParams ep,
-                                                              int M, int N, int K, int nMt, int nNt, int kchunk) {
-  constexpr int BM = 256, BN = 256;
-  constexpr int PLANE_A = LA::PLANE, PLANE_B = LB::PLANE;  // halfwords
-  constexpr int BUF = 2 * (PLANE_A + PLANE_B);
-  static_assert(2 * BUF * 2 <= 160 * 1024, "two buffers must fit the CU's LDS");
-  static_assert(BUF * 2 >= 8 * 32 * 64 * 4, "operand LDS too small to stage the epilogue");
-  __shared__ __attribute__((aligned(16))) unsigned short smem16[2 * BUF];
-
-  int mt, nt;
-  tile_coords(nMt, nNt, mt, nt);
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int z = blockIdx.y;
-  const int kbeg = z * kchunk;
-  const int kend = min(K, kbeg + kchunk);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-
-  LA la; LB lb;
-  la.init(pa, m0, tid);
-  lb.init(pb, n0, tid);
-
-  f32x16 acc0[2][2], acc1[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
-
-  float4 ra[LA::NV], rb[LB::NV];
-  la.load(kbeg, ra, kbeg < kend); lb.load(kbeg, rb, kbeg < kend);
-  la.store2(smem16, smem16 + PLANE_A, ra); lb.store2(smem16 + 2 * PLANE_A, smem16 + 2 * PLANE_A + PLANE_B, rb);
-  la.load(kbeg + BK, ra, kbeg + BK < kend); lb.load(kbeg + BK, rb, kbeg + BK < kend);
-  __syncthreads();
-
-  int cur = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const unsigned short* c = smem16 + cur * BUF;
-    unsigned short* n = smem16 + (cur ^ 1) * BUF;
-    const bool has2 = (k0 + 2 * BK < kend) && !(CXRK_ABL & 1);
-    if (!(CXRK_ABL & 2)) la.store2(n, n + PLANE_A, ra);          // A(t+1): registers -> the other buffer ...
-    la.load(k0 + 2 * BK, ra, has2);                               // ... and re-load them with A(t+2) at once
-    x3w_mfma_block<LA, LB>(c, c + PLANE_A, c + 2 * PLANE_A, c + 2 * PLANE_A + PLANE_B, wm, wn, 0, lane, acc0, acc1);
-    if (!(CXRK_ABL & 2)) lb.store2(n + 2 * PLANE_A, n + 2 * PLANE_A + PLANE_B, rb);
-    lb.load(k0 + 2 * BK, rb, has2);
-    x3w_mfma_block<LA, LB>(c, c + PLANE_A, c + 2 * PLANE_A, c + 2 * PLANE_A + PLANE_B, wm, wn, 1, lane, acc0, acc1);
-    __syncthreads();
-    cur ^= 1;
-  }
-  if ((CXRK_ABL & 4) && acc0[0][0][0] != 12345.678f) return;
-  float* st = reinterpret_cast<float*>(smem16) + wave * (32 * 64);
-  gemm_epilogue64(acc0, ep, st, M, N, m0 + wm * 128, n0 + wn * 64, mt * 4 + wm * 2, z, lane);
-  gemm_epilogue64(acc1, ep, st, M, N, m0 + wm * 128 + 64, n0 + wn * 64, mt * 4 + wm * 2 + 1, z, lane);
-}
-
 // 0 = exact fp32 MFMA (default), 1 = split-bf16.  Process-wide, set through cxrk_set_precision().
 inline int& gemm_precision_mode() { static int mode = 0; return mode; }
 
@@ -580,12 +459,15 @@ static inline int stream_output(int M, int N, int splitk) {
   return (double)M * N * 4.0 * (splitk > 1 ? splitk : 1) >= thr;
 }
 
-// 256x256-tile policy.  CXRK_WIDE (environment, read once): 0 = never, 1 (default) = where it pays, 2 = wherever the
-// precision mode allows it (test coverage on small shapes).  "Pays": split-bf16 launch, both tile dimensions filled, a K
+int wgrad_splitk_policy(int M, int N, int K, bool planes);   // gemm.hip
+
+// 256x256-tile policy.  CXRK_WIDE (environment, read once; cxrk_set_wide_mode() at run time): 0 = never, 1 (default) = where it
+// pays, 2 = every launch on planes operands (test coverage on small / ragged shapes).  "Pays": split-bf16 launch, both tile dimensions filled, a K
 // loop long enough to amortise the exposed prologue / epilogue of a one-block-per-CU kernel, and a tile count that fills
 // the 256 CUs in whole rounds to at least 60 % (the other encoder's stream fills a partial round: 80 -> 70 % was worth 3 % of
 // the step, below 60 % nothing more).
-inline int wide_mode() { static const int m = [] { const char* e = getenv("CXRK_WIDE"); return e ? atoi(e) : 1; }(); return m; }
+inline int& wide_mode_ref() { static int m = [] { const char* e = getenv("CXRK_WIDE"); return e ? atoi(e) : 1; }(); return m; }
+inline int wide_mode() { return wide_mode_ref(); }
 // min_k: shortest K loop (per split-K slab) for which the caller's kind of launch gains (measured per kind on the step's
 // shapes, scripts/layer_table.py: the heavier the fused epilogue, the longer the loop has to be to pay for exposing it).
 static inline long env_long(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
@@ -596,10 +478,11 @@ inline long wide_mink(int kind) {
   static const long v[3] = {env_long("CXRK_MINK_PLAIN", 512), env_long("CXRK_MINK_FPROP", 512), env_long("CXRK_MINK_DGRAD", 1024)};
   return v[kind];
 }
-static inline bool use_wide256(int M, int N, long K, int splitk, bool force_fp32 = false, long min_k = WIDE_MINK_PLAIN) {
-  if (gemm_precision_mode() != 1 || force_fp32 || 2.0 * M * N * (double)K < 1073741824.0) return false;
+static inline bool use_wide256(int M, int N, long K, int splitk, bool planes, long min_k = WIDE_MINK_PLAIN) {
+  if (!planes) return false;                     // the 256x256 kernel (gemm_pw.h) reads planes operands
   const int mode = wide_mode();
-  if (mode == 2) return true;
+  if (mode == 2) return true;                    // test coverage: every planes launch, ragged and tiny ones included
+  if (2.0 * M * N * (double)K < 1073741824.0) return false;
   if (mode == 0 || M < 256 || N < 256) return false;
   const long kper = splitk > 1 ? K / splitk : K;
   if (kper < min_k) return false;
@@ -609,23 +492,26 @@ static inline bool use_wide256(int M, int N, long K, int splitk, bool force_fp32
   return tiles * 100 >= rounds * 256 * eff_pct;
 }
 
-template <class LA, class LB>
-static int launch_gemm_wide(const typename LA::P& pa, const typename LB::P& pb, const EpiParams& ep, int M, int N, int K,
-                            int splitk, hipStream_t stream) {
-  if (M <= 0 || N <= 0 || K <= 0) return CXRK_ERR_ARG;
-  const int nMt = ceil_div(M, 256), nNt = ceil_div(N, 256);
-  int kchunk = K;
-  if (splitk > 1) { kchunk = ceil_div(ceil_div(K, splitk), BK) * BK; splitk = ceil_div(K, kchunk); }
-  else splitk = 1;
-  dim3 grid((unsigned)(nMt * nNt), (unsigned)splitk, 1);
-  EpiParams e = ep;
+// Fills the launch-derived epilogue switches; false = the operand formats / alignments cannot be served.
+static inline bool prep_epilogue(EpiParams& e, int M, int N, int splitk) {
   auto ok16 = [](const void* p_, long ld) { return p_ == nullptr || (aligned16(p_) && (ld % 4) == 0); };
+  auto ok8 = [](const void* p_, long ld) { return p_ == nullptr || (aligned16(p_) && (ld % 8) == 0); };
   e.vec = (N % 4 == 0) && ok16(e.C, e.ldc) && ((e.slab_stride % 4) == 0) && ok16(e.R, e.ldr) && ok16(e.aux, e.ldaux) &&
           ok16(e.C2, e.ldc2) && (e.bias == nullptr || aligned16(e.bias));
+  e.pl = (e.Cp || e.Rp || e.maskin || e.maskout || e.auxmode == 3) ? 1 : 0;
+  e.fast = e.vec && (N % 8) == 0 && ok8(e.Cp, e.ldc) && ok8(e.Rp, e.ldr) && (e.cplane % 8) == 0 && (e.rplane % 8) == 0 &&
+           (!e.maskout || ((N % 64) == 0 && (e.ldmaskout % 8) == 0 && (((uintptr_t)e.maskout) & 7) == 0));
+  e.kind = epi_kind(epi_flags(e));
+  if (e.pl) {   // planes / mask operands exist in the fast epilogue only
+    if (!e.fast) return false;
+    if ((e.C != nullptr) == (e.Cp != nullptr)) return false;           // exactly one output format
+    if (e.R && e.Rp) return false;
+    if (e.auxmode == 3 && !e.maskin) return false;
+    if (e.maskout && e.act != 1) return false;
+    if (e.Cp && splitk > 1) return false;                               // split-K slabs are fp32
+  }
   e.nt = stream_output(M, N, splitk);
-  hipLaunchKernelGGL((gemm_x3w_kernel<LA, LB>), grid, dim3(NT_WIDE), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
-  CXRK_LAUNCH_CHECK();
-  return splitk;
+  return true;
 }
 
 // Host launcher.  splitk > 1 writes plain partial slabs (caller reduces them).
@@ -640,14 +526,16 @@ static int launch_gemm(const typename LA::P& pa, const typename LB::P& pb, const
   else splitk = 1;
   dim3 grid((unsigned)(nMt * nNt), (unsigned)splitk, 1);
   EpiParams e = ep;
-  auto ok16 = [](const void* p_, long ld) { return p_ == nullptr || (aligned16(p_) && (ld % 4) == 0); };
-  e.vec = (N % 4 == 0) && ok16(e.C, e.ldc) && ((e.slab_stride % 4) == 0) && ok16(e.R, e.ldr) && ok16(e.aux, e.ldaux) &&
-          ok16(e.C2, e.ldc2) && (e.bias == nullptr || aligned16(e.bias));
+  if (!prep_epilogue(e, M, N, splitk)) return CXRK_ERR_ARG;
   // split-bf16 only where it pays and is well conditioned: small problems (adapters, heads: < 1 GFLOP) and launches the
-  // caller marks exact (the stem convolution: an all-positive input makes its weight gradient a cancelling sum) stay fp32
-  const bool split = gemm_precision_mode() == 1 && !force_fp32 && 2.0 * M * N * (double)K >= 1073741824.0;
-  e.nt = stream_output(M, N, splitk);
-  if (split)
+  // caller marks exact (the stem convolution: an all-positive input makes its weight gradient a cancelling sum) stay fp32.
+  // Pre-split ("planes") operands exist in the split-bf16 format only: they always take the split mainloop.
+  constexpr bool planes_in = LA::FMT_PLANES || LB::FMT_PLANES;
+  const bool split = planes_in || (gemm_precision_mode() == 1 && !force_fp32 && 2.0 * M * N * (double)K >= 1073741824.0);
+  if constexpr (planes_in) {
+    static_assert(LA::FMT_PLANES && LB::FMT_PLANES, "both operands must share the storage format");
+    hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
+  } else if (split)
     hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
   else
     hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
@@ -656,3 +544,4 @@ static int launch_gemm(const typename LA::P& pa, const typename LB::P& pb, const
 }
 
 }  // namespace cxrk
+#include "gemm_pw.h"

@@ -1,0 +1,276 @@
+// Epilogue of the MFMA mainloops for 16-byte-aligned operands (every shape of the training step): included by gemm_core.h.
+//
+// One wave owns a 64x64 output sub-tile in 2x2 accumulator tiles of the 32x32 MFMA C/D map (col = lane & 31,
+// row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)): a lane holds ONE column.  Stored from there it would take 64 dword stores
+// per lane in 128-byte pieces; instead the wave transposes 32 rows at a time through its private 8 KiB of (now free) operand
+// LDS and leaves with 8 consecutive columns per lane: 16-byte pieces of every operand, fp32 (two per lane) or bf16 planes.
+//
+// Round 1's epilogue decided everything (operand formats, activation, residual, masks, row remap, ragged edges) with
+// run-time branches per element group; s_memtime stamps put it at 85,000 cycles per 256x256 tile — as long as 24 K-tiles of
+// the mainloop — for ~1,000 useful instructions per wave: it spilled scalar registers into vector lanes and re-derived the
+// predicates per row.  This version
+//  * is a template over the feature set F: the flag combinations the training step uses are compiled in (EPI_KINDS) and picked
+//    by ONE switch; every other combination runs the same code with F = EF_GENERIC, where each feature test is a (wave-uniform)
+//    run-time test of the parameter block;
+//  * never branches per lane: every global access is a buffer load / store whose lane offset carries bit 31 when the lane's row
+//    or column is outside the tensor (descriptors declare 2^31 bytes: the range check drops the access);
+//  * issues the side-input loads of all four 8-row passes of a 32-row half before the first store of that half.
+// The row-remapped form (stride-2 data-gradient parity classes) addresses rows individually and is predicated instead.
+#pragma once
+
+namespace cxrk {
+
+enum : unsigned {
+  EF_OUTPL = 1u << 0,      // output as bf16 hi/lo planes (else fp32)
+  EF_BIAS = 1u << 1,
+  EF_RES_F32 = 1u << 2,    // residual fp32
+  EF_RES_PL = 1u << 3,     // residual planes
+  EF_RELU = 1u << 4,
+  EF_GELU = 1u << 5,
+  EF_AUX_SIGN = 1u << 6,   // v *= (aux > 0), aux fp32          (auxmode 1)
+  EF_AUX_GELU = 1u << 7,   // v *= gelu'(aux), aux fp32         (auxmode 2)
+  EF_AUX_MASK = 1u << 8,   // v *= bit of maskin                (auxmode 3)
+  EF_C2 = 1u << 9,         // fp32 copy of the pre-activation value
+  EF_MASKOUT = 1u << 10,   // store the ReLU decision bits
+  EF_COLSUM = 1u << 11,    // per-wave column sums of the stored values
+  EF_REMAP = 1u << 12,     // output-row remap (stride-2 dgrad parity class)
+  EF_GENERIC = 1u << 31,   // every feature decided at run time
+};
+
+// Feature sets compiled in (index = EpiParams::kind); anything else runs as EF_GENERIC.
+constexpr unsigned EPI_KINDS[] = {
+    0u,                                                          //  0 plain fp32: split-K slabs, weight gradients, dctx
+    EF_BIAS,                                                     //  1 qkv projection
+    EF_BIAS | EF_RES_PL,                                         //  2 attention output / FFN down projection (+ residual)
+    EF_OUTPL | EF_BIAS | EF_GELU | EF_C2,                        //  3 FFN up projection
+    EF_OUTPL | EF_AUX_GELU,                                      //  4 gradient through GELU
+    EF_RES_PL,                                                   //  5 data gradient + residual gradient
+    EF_OUTPL | EF_BIAS | EF_RELU | EF_MASKOUT,                   //  6 conv + BN + ReLU
+    EF_OUTPL | EF_BIAS | EF_RES_PL | EF_RELU | EF_MASKOUT,       //  7 conv + BN + identity + ReLU
+    EF_OUTPL | EF_BIAS,                                          //  8 downsample conv + BN
+    EF_OUTPL | EF_AUX_MASK | EF_COLSUM,                          //  9 conv data gradient, ReLU mask, beta-gradient sums
+    EF_OUTPL | EF_RES_PL | EF_AUX_MASK | EF_COLSUM,              // 10 the same + gradient of the identity branch
+    EF_OUTPL,                                                    // 11 plain planes output
+    EF_BIAS | EF_RELU,                                           // 12 fp32 mode: conv + BN + ReLU
+    EF_BIAS | EF_RES_F32 | EF_RELU,                              // 13 fp32 mode: conv + BN + identity + ReLU
+    EF_AUX_SIGN | EF_COLSUM,                                     // 14 fp32 mode: conv data gradient
+    EF_RES_F32 | EF_AUX_SIGN | EF_COLSUM,                        // 15 fp32 mode: conv data gradient + identity gradient
+    EF_BIAS | EF_RES_F32,                                        // 16 fp32 mode: dense + residual
+    EF_BIAS | EF_GELU | EF_C2,                                   // 17 fp32 mode: FFN up projection
+    EF_RES_F32,                                                  // 18 fp32 mode: data gradient + residual gradient
+    EF_OUTPL | EF_BIAS | EF_RELU,                                // 19 stem conv + BN + ReLU (its mask is the sign of the pooled value)
+};
+constexpr int EPI_NKINDS = (int)(sizeof(EPI_KINDS) / sizeof(EPI_KINDS[0]));
+
+// host: feature word of a parameter block / its compiled-in index (-1: generic)
+static inline unsigned epi_flags(const EpiParams& e) {
+  unsigned f = 0;
+  if (e.Cp) f |= EF_OUTPL;
+  if (e.bias) f |= EF_BIAS;
+  if (e.R) f |= EF_RES_F32;
+  if (e.Rp) f |= EF_RES_PL;
+  if (e.act == 1) f |= EF_RELU;
+  if (e.act == 2) f |= EF_GELU;
+  if (e.auxmode == 1) f |= EF_AUX_SIGN;
+  if (e.auxmode == 2) f |= EF_AUX_GELU;
+  if (e.auxmode == 3) f |= EF_AUX_MASK;
+  if (e.C2) f |= EF_C2;
+  if (e.maskout) f |= EF_MASKOUT;
+  if (e.colsum_part) f |= EF_COLSUM;
+  if (e.rm_on) f |= EF_REMAP;
+  return f;
+}
+static inline int epi_kind(unsigned flags) {
+  for (int i = 0; i < EPI_NKINDS; ++i) if (EPI_KINDS[i] == flags) return i;
+  return -1;
+}
+
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff) { return bloadu4(r, voff); }
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, unsigned voff, const uint4& v, bool nt) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 u = {v.x, v.y, v.z, v.w};
+  if (nt) __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)voff, 0, 2);   // aux 2 = nt
+  else __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)voff, 0, 0);
+}
+__device__ __forceinline__ uint4 f4_bits(float a, float b, float c, float d) {
+  return make_uint4(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
+}
+
+#define EH(bit, rt) (GEN ? (rt) : ((F & (bit)) != 0u))
+
+template <unsigned F>
+__device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0, int col0,
+                                      int part, int z, int lane) {
+  constexpr bool GEN = (F & EF_GENERIC) != 0u;
+  const bool outpl = EH(EF_OUTPL, ep.Cp != nullptr), has_bias = EH(EF_BIAS, ep.bias != nullptr);
+  const bool res_f32 = EH(EF_RES_F32, ep.R != nullptr), res_pl = EH(EF_RES_PL, ep.Rp != nullptr);
+  const bool relu = EH(EF_RELU, ep.act == 1), gelu = EH(EF_GELU, ep.act == 2);
+  const bool aux_sign = EH(EF_AUX_SIGN, ep.auxmode == 1), aux_gelu = EH(EF_AUX_GELU, ep.auxmode == 2), aux_mask = EH(EF_AUX_MASK, ep.auxmode == 3);
+  const bool has_c2 = EH(EF_C2, ep.C2 != nullptr), maskout = EH(EF_MASKOUT, ep.maskout != nullptr);
+  const bool colsum = EH(EF_COLSUM, ep.colsum_part != nullptr), remap = EH(EF_REMAP, ep.rm_on != 0);
+  const bool nt = ep.nt != 0;
+
+  const int r = lane & 31, h = lane >> 5;
+  const int c8 = lane & 7, rq = lane >> 3;
+  const int col = col0 + c8 * 8;
+  const bool colok = col < N;
+  const unsigned deadcol = colok ? 0u : VOFF_OOB;
+
+  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (has_bias) {
+    const __amdgpu_buffer_rsrc_t rb = tile_rsrc(ep.bias + col0);
+    const uint4 b0 = buf_load16(rb, (unsigned)(c8 * 32) | deadcol), b1 = buf_load16(rb, (unsigned)(c8 * 32 + 16) | deadcol);
+    bv[0] = __builtin_bit_cast(float, b0.x); bv[1] = __builtin_bit_cast(float, b0.y); bv[2] = __builtin_bit_cast(float, b0.z); bv[3] = __builtin_bit_cast(float, b0.w);
+    bv[4] = __builtin_bit_cast(float, b1.x); bv[5] = __builtin_bit_cast(float, b1.y); bv[6] = __builtin_bit_cast(float, b1.z); bv[7] = __builtin_bit_cast(float, b1.w);
+  }
+  float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // Wave-uniform descriptors at the sub-tile origin (row0, col0); lane offsets below are relative to it.  In the remapped form
+  // (GEMM row (n,a,b) -> pixel (n, 2a+ph, 2b+pw)) the origin is the pixel of the sub-tile's first row and a lane adds the
+  // distance of its own pixel from it (the map is monotonic, and 64 consecutive GEMM rows stay within a few image rows).
+  const long rbase = remap ? epi_row(ep, row0 < M ? row0 : M - 1) : (long)row0;   // remap is monotonic: lane offsets stay >= 0
+  float* Cf = ep.C ? ep.C + (long)z * ep.slab_stride : nullptr;
+  const __amdgpu_buffer_rsrc_t d_out = tile_rsrc(outpl ? (const void*)(ep.Cp + rbase * ep.ldc + col0) : (const void*)(Cf + rbase * ep.ldc + col0));
+  const __amdgpu_buffer_rsrc_t d_out2 = tile_rsrc(outpl ? (const void*)(ep.Cp + ep.cplane + rbase * ep.ldc + col0) : (const void*)nullptr, outpl);
+  const __amdgpu_buffer_rsrc_t d_res = tile_rsrc(res_pl ? (const void*)(ep.Rp + rbase * ep.ldr + col0) : (const void*)(ep.R + rbase * ep.ldr + col0), res_pl || res_f32);
+  const __amdgpu_buffer_rsrc_t d_res2 = tile_rsrc(res_pl ? (const void*)(ep.Rp + ep.rplane + rbase * ep.ldr + col0) : (const void*)nullptr, res_pl);
+  const __amdgpu_buffer_rsrc_t d_aux = tile_rsrc(ep.aux + rbase * ep.ldaux + col0, aux_sign || aux_gelu);
+  const __amdgpu_buffer_rsrc_t d_c2 = tile_rsrc(ep.C2 + rbase * ep.ldc2 + col0, has_c2);
+  const __amdgpu_buffer_rsrc_t d_min = tile_rsrc(ep.maskin + rbase * ep.ldmaskin + (col0 >> 3), aux_mask);
+  const __amdgpu_buffer_rsrc_t d_mout = tile_rsrc(ep.maskout + rbase * ep.ldmaskout + (col0 >> 3), maskout);
+  const unsigned osz = outpl ? 2u : 4u;
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[((e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[i][j][e];
+    __builtin_amdgcn_wave_barrier();  // LDS serves one wave's accesses in issue order; keep the compiler from reordering
+
+    // ---- side inputs of PF 8-row passes at a time (all four of this half in the compiled-in feature sets; the generic form, which
+    //      may carry every side input at once, goes pass by pass to stay inside the register budget)
+    constexpr int PF = GEN ? 1 : 4;
+#pragma unroll
+    for (int ug = 0; ug < 4; ug += PF) {
+    unsigned dead[PF]; long rows[PF];
+    uint4 r0v[PF], r1v[PF], a0v[PF], a1v[PF]; unsigned mk[PF];
+#pragma unroll
+    for (int up = 0; up < PF; ++up) {
+      const int u = up, ua = ug + up;
+      const int rl = i * 32 + ua * 8 + rq;              // row inside the sub-tile
+      const int grow = row0 + rl;
+      dead[u] = (grow < M ? 0u : VOFF_OOB) | deadcol;
+      rows[u] = remap ? epi_row(ep, grow < M ? grow : M - 1) - rbase : (long)rl;
+      const unsigned rowo = (unsigned)rows[u];
+      if (res_pl) {
+        const unsigned o = ((rowo * (unsigned)ep.ldr + c8 * 8) * 2u) | dead[u];
+        r0v[u] = buf_load16(d_res, o); r1v[u] = buf_load16(d_res2, o);
+      } else if (res_f32) {
+        const unsigned o = ((rowo * (unsigned)ep.ldr + c8 * 8) * 4u) | dead[u];
+        r0v[u] = buf_load16(d_res, o); r1v[u] = buf_load16(d_res, o + 16u);
+      }
+      if (aux_sign || aux_gelu) {
+        const unsigned o = ((rowo * (unsigned)ep.ldaux + c8 * 8) * 4u) | dead[u];
+        a0v[u] = buf_load16(d_aux, o); a1v[u] = buf_load16(d_aux, o + 16u);
+      }
+      if (aux_mask) mk[u] = __builtin_amdgcn_raw_buffer_load_b8(d_min, (int)((rowo * (unsigned)ep.ldmaskin + c8) | dead[u]), 0, 0);
+    }
+    // ---- values, stores
+#pragma unroll
+    for (int up = 0; up < PF; ++up) {
+      const int u = up, ua = ug + up;
+      const float* sp = st + (ua * 8 + rq) * 64 + c8 * 8;
+      const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+      float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      const unsigned rowo = (unsigned)rows[u];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = ep.alpha * v[q] + bv[q];
+      if (res_pl) {
+        float rv[8]; planes_unpack8(r0v[u], r1v[u], rv);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+      } else if (res_f32) {
+        const unsigned rw[8] = {r0v[u].x, r0v[u].y, r0v[u].z, r0v[u].w, r1v[u].x, r1v[u].y, r1v[u].z, r1v[u].w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += __builtin_bit_cast(float, rw[q]);
+      }
+      if (has_c2) {
+        const unsigned o = ((rowo * (unsigned)ep.ldc2 + c8 * 8) * 4u) | dead[u];
+        buf_store16(d_c2, o, f4_bits(v[0], v[1], v[2], v[3]), false);
+        buf_store16(d_c2, o + 16u, f4_bits(v[4], v[5], v[6], v[7]), false);
+      }
+      unsigned obits = 0;
+      if (relu) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { obits |= (v[q] > 0.f ? 1u : 0u) << q; v[q] = fmaxf(v[q], 0.f); }
+      } else if (gelu) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = gelu_erf(v[q]);
+      }
+      if (aux_mask) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = ((mk[u] >> q) & 1u) ? v[q] : 0.f;
+      } else if (aux_sign || aux_gelu) {
+        const unsigned aw[8] = {a0v[u].x, a0v[u].y, a0v[u].z, a0v[u].w, a1v[u].x, a1v[u].y, a1v[u].z, a1v[u].w};
+        if (aux_sign) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = __builtin_bit_cast(float, aw[q]) > 0.f ? v[q] : 0.f;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] *= gelu_erf_grad(__builtin_bit_cast(float, aw[q]));
+        }
+      }
+      if (colsum) {
+        const bool livel = dead[u] == 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bs[q] += livel ? v[q] : 0.f;
+      }
+      const unsigned oo = ((rowo * (unsigned)ep.ldc + c8 * 8) * osz) | dead[u];
+      if (outpl) {
+        uint4 hv, lv; planes_pack8(v, hv, lv);
+        buf_store16(d_out, oo, hv, nt); buf_store16(d_out2, oo, lv, nt);
+      } else {
+        buf_store16(d_out, oo, f4_bits(v[0], v[1], v[2], v[3]), nt);
+        buf_store16(d_out, oo + 16u, f4_bits(v[4], v[5], v[6], v[7]), nt);
+      }
+      if (maskout) {   // the 8 lanes of a row hold its 8 mask bytes: OR them together, lane c8 == 0 stores the 8 bytes
+        unsigned w0 = c8 < 4 ? obits << (8 * c8) : 0u, w1 = c8 >= 4 ? obits << (8 * (c8 - 4)) : 0u;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { w0 |= (unsigned)__shfl_xor((int)w0, o, 64); w1 |= (unsigned)__shfl_xor((int)w1, o, 64); }
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 w = {w0, w1};
+        const int grow = row0 + i * 32 + ua * 8 + rq;
+        const unsigned mo = (rowo * (unsigned)ep.ldmaskout) | ((c8 == 0 && grow < M && col0 < N) ? 0u : VOFF_OOB);
+        __builtin_amdgcn_raw_buffer_store_b64(w, d_mout, (int)mo, 0, 0);
+      }
+    }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (colsum) {  // add the eight row lanes of the wave (lanes c8 + 8*rq), lanes 0..7 write
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float t = bs[q];
+      t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+      bs[q] = t;
+    }
+    const __amdgpu_buffer_rsrc_t d_cs = tile_rsrc(ep.colsum_part + (long)part * N + col0);
+    const unsigned o = (unsigned)(c8 * 32) | ((rq == 0 && colok) ? 0u : VOFF_OOB);
+    buf_store16(d_cs, o, f4_bits(bs[0], bs[1], bs[2], bs[3]), false);
+    buf_store16(d_cs, o + 16u, f4_bits(bs[4], bs[5], bs[6], bs[7]), false);
+  }
+}
+#undef EH
+
+template <int KIND>
+__device__ __forceinline__ void epi64_dispatch(int kind, f32x16 (&acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0,
+                                               int col0, int part, int z, int lane) {
+  if constexpr (KIND >= EPI_NKINDS) epi64<EF_GENERIC>(acc, ep, st, M, N, row0, col0, part, z, lane);
+  else {
+    if (kind == KIND) epi64<EPI_KINDS[KIND]>(acc, ep, st, M, N, row0, col0, part, z, lane);
+    else epi64_dispatch<KIND + 1>(kind, acc, ep, st, M, N, row0, col0, part, z, lane);
+  }
+}
+
+}  // namespace cxrk

@@ -1,0 +1,57 @@
+// Dense GEMM entry point on split-bf16 planes tensors (the encoders in split-bf16 mode): 256x256 LDS-DMA kernel where the policy
+// picks it, 128x128-class tiles otherwise.
+#include "gemm_common.h"
+
+using namespace cxrk;
+
+template <template <int, class, int> class LAT, template <int, class, int> class LBT, class DLA, class DLB>
+static int dense_planes(const unsigned short* A, long lda, long aplane, const unsigned short* B, long ldb, long bplane, const EpiParams& ep,
+                        int M, int N, int K, int splitk, hipStream_t stream) {
+  if (use_wide256(M, N, K, splitk, true)) {
+    typename DLA::P pa{A, lda, M, K, aplane}; typename DLB::P pb{B, ldb, N, K, bplane};
+    return launch_gemm_pw<DLA, DLB>(pa, pb, ep, M, N, K, splitk, stream);
+  }
+  return dense_small<PL, LAT, LBT>(A, lda, aplane, B, ldb, bplane, ep, M, N, K, splitk, stream);
+}
+
+// Same contraction on pre-split ("planes") operands: A and B are bf16 hi/lo plane pairs (lo plane `aplane` / `bplane` elements
+// behind the hi plane), the output is either fp32 (C) or planes (Cp, `cplane`), the residual either fp32 (R) or planes (Rp).
+// auxmode 2 = multiply by gelu'(aux) (aux fp32), 3 = multiply by the ReLU decision bits `maskin` (byte [row][col / 8]);
+// `maskout` (with act 1) receives the decision bits of this launch's own ReLU.
+extern "C" int cxrk_gemm_pl(int transA, int transB, int M, int N, int K, const void* A, long lda, long aplane, const void* B,
+                            long ldb, long bplane, float* C, void* Cp, long ldc, long cplane, const float* bias, const float* R,
+                            const void* Rp, long ldr, long rplane, const float* aux, long ldaux, int auxmode,
+                            const unsigned char* maskin, long ldmaskin, unsigned char* maskout, long ldmaskout, float* C2,
+                            long ldc2, int act, float alpha, int accumulate, int splitk, float* ws, size_t ws_bytes,
+                            hipStream_t stream) {
+  CXRK_CHECK_ARG(A && B && (C || Cp) && M > 0 && N > 0 && K > 0);
+  CXRK_CHECK_ARG(aligned16(A) && aligned16(B) && (lda % 8 == 0) && (ldb % 8 == 0) && (aplane % 8 == 0) && (bplane % 8 == 0));
+  CXRK_CHECK_ARG(transA ? (M % 8 == 0) : (K % 8 == 0));
+  CXRK_CHECK_ARG(transB ? (K % 8 == 0) : (N % 8 == 0));
+  CXRK_CHECK_ARG(!(transA && transB));                      // not needed on this path
+  CXRK_CHECK_ARG(auxmode == 0 || (auxmode == 2 && aux) || (auxmode == 3 && maskin));
+  if (lda >= (1L << 20) || ldb >= (1L << 20)) return CXRK_ERR_UNSUPPORTED;
+  if (splitk < 1) splitk = 1;
+  EpiParams ep{};
+  ep.alpha = alpha;
+  const bool plain = !bias && !R && !Rp && !aux && !maskin && !maskout && !C2 && act == 0;
+  if (splitk > 1) {
+    CXRK_CHECK_ARG(plain && C && !Cp && (N % 4 == 0));
+    if (ws == nullptr || ws_bytes < cxrk_gemm_splitk_ws_bytes(M, N, splitk)) return CXRK_ERR_WS;
+    ep.C = ws; ep.ldc = N; ep.alpha = 1.f; ep.slab_stride = (long)M * N;
+  } else {
+    if (accumulate) { CXRK_CHECK_ARG(R == nullptr && Rp == nullptr && C); ep.R = C; ep.ldr = ldc; }
+    else { ep.R = R; ep.Rp = static_cast<const unsigned short*>(Rp); ep.ldr = ldr; ep.rplane = rplane; }
+    ep.C = C; ep.Cp = static_cast<unsigned short*>(Cp); ep.ldc = ldc; ep.cplane = cplane; ep.bias = bias;
+    ep.aux = aux; ep.ldaux = ldaux; ep.auxmode = auxmode; ep.maskin = maskin; ep.ldmaskin = ldmaskin;
+    ep.maskout = maskout; ep.ldmaskout = ldmaskout; ep.C2 = C2; ep.ldc2 = ldc2; ep.act = act;
+  }
+  const unsigned short* Ap = static_cast<const unsigned short*>(A);
+  const unsigned short* Bp = static_cast<const unsigned short*>(B);
+  int rc;
+  if (!transA && transB) rc = dense_planes<DenseKC, DenseKC, DmaDenseKC, DmaDenseKC>(Ap, lda, aplane, Bp, ldb, bplane, ep, M, N, K, splitk, stream);
+  else if (!transA && !transB) rc = dense_planes<DenseKC, DenseMC, DmaDenseKC, DmaDenseMC>(Ap, lda, aplane, Bp, ldb, bplane, ep, M, N, K, splitk, stream);
+  else rc = dense_planes<DenseMC, DenseMC, DmaDenseMC, DmaDenseMC>(Ap, lda, aplane, Bp, ldb, bplane, ep, M, N, K, splitk, stream);
+  return finish_splitk(rc, splitk, M, N, ws, C, ldc, alpha, accumulate, stream);
+}
+

@@ -1,0 +1,546 @@
+// 256x256 split-bf16 mainloop for pre-split ("planes") operands: LDS-DMA staging + software-pipelined fragment reads.
+// (Included at the end of gemm_core.h.)
+//
+// Why a second wide kernel.  With planes operands the register-staged 256x256 kernel (gemm_x3w_kernel) has no conversion work
+// left, yet it stays at ~35 % of the matrix pipe: its waves read ALL fragments of a K-step, then issue its 24 MFMAs, then
+// store the next tile to LDS, and the two waves that share a SIMD do that in lockstep, so the matrix pipe idles during every
+// read / store phase (round-1 ablation: MFMAs alone 666 TFLOP/s, + fragment reads 485-520, + stores ~400, + global loads ~310).
+// Here
+//  * operand tiles go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging registers, no ds_write pass, and the
+//    range-checked zero fill of out-of-range lanes (bit 31 of the offset; verified on gfx950 by scripts/probe_ldsdma.hip: a lane
+//    outside the descriptor writes ZERO to LDS) still implements tile edges, convolution halos and K tails;
+//  * an LDS-DMA piece is lane-linear (wave-uniform base + 16 B x lane), so the bank-conflict-free layouts are obtained by
+//    permuting the per-lane SOURCE addresses (cdna_hip_programming.md rule 21): K-contiguous planes are [row][64 B] with the four
+//    16-byte k-chunks of row r XOR-ed by (r >> 2) & 3 (conflict-free ds_read_b128 for the 32x32x16 operand map);
+//    idx-contiguous planes are [k][2*TILE B] with the 64-byte column groups of k-row k XOR-ed by (k & 3) (conflict-free
+//    ds_read_b64_tr_b16 blocks);
+//  * the 48 MFMAs of a K-tile are issued as four groups of 12; the fragments of group g+1 are read while group g computes
+//    (two register sets), the DMA of the next tile is issued during groups 0 and 1, and the ONE barrier of the K-tile sits
+//    before the last group, whose MFMAs then cover the first fragment reads of the next tile: no phase of the loop is without
+//    matrix work in flight.
+// Hazards (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait that retires it"):
+//    RAW  tile t+1 is DMA-ed during groups 0-1 of tile t; every wave waits vmcnt(0) and then passes the barrier before any
+//         wave reads it;
+//    WAR  the DMA of tile t+2 overwrites the buffer of tile t; it is issued after that barrier, which every wave reaches only
+//         after lgkmcnt(0) has retired its last fragment reads of tile t (those of group 3, issued in group 2).
+#pragma once
+
+namespace cxrk {
+
+constexpr int PW_PLANE = 256 * BK * 2;      // bytes of one bf16 plane of a 256 x BK operand tile (16 KiB)
+constexpr int PW_STAGE = 4 * PW_PLANE;      // A hi | A lo | B hi | B lo (64 KiB); two stages = 128 KiB of the CU's 160 KiB
+constexpr int PW_NT = 512;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned char* lds_wave_uniform, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds_wave_uniform, 16, (int)voff, 0, 0, 0);
+}
+
+// ---- fragment reads of the swizzled LDS images ---------------------------------------------------------------------
+// K-contiguous plane [row][4 chunks of 16 B]: MFMA 32x32x16 operand (8 bf16 = k 8h .. 8h+7 of k-step kc) of row row0 + (lane & 31)
+__device__ __forceinline__ bf16x8 pw_frag_kc(const unsigned char* plane, int row0, int kc, int lane) {
+  const int r = row0 + (lane & 31);
+  const int q = (2 * kc + (lane >> 5)) ^ ((lane >> 2) & 3);
+  return *reinterpret_cast<const bf16x8*>(plane + r * 64 + q * 16);
+}
+// idx-contiguous plane [k][512 B]: two transposing reads (see frag_mc in gemm_core.h for the lane map)
+__device__ __forceinline__ bf16x8 pw_frag_mc(const unsigned char* plane, int row0, int kc, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+  const int k = kc * 16 + 8 * (g >> 1) + q;                             // k & 3 == q, also for the second read (k + 4)
+  const int colb = ((row0 + 16 * (g & 1) + 4 * pp) * 2) ^ (q << 6);
+  const unsigned char* a0 = plane + k * 512 + colb;
+  typedef s16x4 __attribute__((address_space(3))) * lds_v4;
+  const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a0));
+  const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a0 + 4 * 512));
+  const s16x8 x = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+  return __builtin_bit_cast(bf16x8, x);
+}
+
+// ---- DMA loaders (planes sources only) -----------------------------------------------------------------------------------
+// Every loader: init(P, idx0, wave, lane); issue(k0, lds_hi, live): this wave's share of the tile (2 pieces per plane).
+// K-contiguous images: wave w fills rows [32w, 32w + 32) of each plane; piece j = 16 rows; lane -> (row 16j + lane/4, slot lane%4),
+// and the slot holds k-chunk q = slot ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3)  (the same for every piece).
+
+// X(idx, k) = ptr[idx*ld + k]
+struct DmaDenseKC {
+  static constexpr bool KC = true;
+  struct P { const unsigned short* ptr; long ld; int rows; int K; long plane; };
+  const unsigned short* bp; long plane; unsigned voff[2]; int kq8, K, wave;
+  __device__ __forceinline__ void init(const P& p, int idx0, int wave_, int lane) {
+    wave = wave_; K = p.K; plane = p.plane;
+    bp = p.ptr + (long)idx0 * p.ld;
+    kq8 = 8 * ((lane & 3) ^ ((lane >> 4) & 3));
+    const int ld = (int)p.ld;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = 32 * wave + 16 * j + (lane >> 2);
+      voff[j] = idx0 + r < p.rows ? (unsigned)((r * ld + kq8) * 2) : VOFF_OOB;
+    }
+  }
+  __device__ __forceinline__ void issue(int k0, unsigned char* lds_hi, bool live) const {
+    const unsigned t = (k0 + BK <= K || k0 + kq8 < K) ? 0u : VOFF_OOB;   // K tail (K % 8 == 0)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + pl * plane + k0, live);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) dma16(rs, lds_hi + pl * PW_PLANE + (32 * wave + 16 * j) * 64, voff[j] | t);
+    }
+  }
+  static __device__ __forceinline__ bf16x8 frag(const unsigned char* plane_, int row0, int kc, int lane) { return pw_frag_kc(plane_, row0, kc, lane); }
+};
+
+// X(idx, k) = ptr[k*ld + idx]: wave w fills k-rows [4w, 4w + 4) of each plane; piece j = 2 k-rows of 512 B; lane -> (k-row 2j + lane/32,
+// LDS bytes 16*(lane%32) ..), which hold the columns at byte (16*(lane%32)) ^ ((k & 3) << 6) of the global row.
+struct DmaDenseMC {
+  static constexpr bool KC = false;
+  struct P { const unsigned short* ptr; long ld; int cols; int K; long plane; };
+  const unsigned short* bp; long plane, ld_; unsigned voff[2]; int kl[2], K, wave;
+  __device__ __forceinline__ void init(const P& p, int idx0, int wave_, int lane) {
+    wave = wave_; K = p.K; plane = p.plane; ld_ = p.ld;
+    bp = p.ptr + idx0;
+    const int ld = (int)p.ld;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = 4 * wave + 2 * j + (lane >> 5);
+      const int colb = (16 * (lane & 31)) ^ ((k & 3) << 6);
+      kl[j] = k;
+      voff[j] = idx0 + colb / 2 < p.cols ? (unsigned)(k * ld * 2 + colb) : VOFF_OOB;   // cols % 8 == 0
+    }
+  }
+  __device__ __forceinline__ void issue(int k0, unsigned char* lds_hi, bool live) const {
+    const bool full = k0 + BK <= K;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + pl * plane + (long)k0 * ld_, live);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) dma16(rs, lds_hi + pl * PW_PLANE + (4 * wave + 2 * j) * 512, (full || k0 + kl[j] < K) ? voff[j] : VOFF_OOB);
+    }
+  }
+  static __device__ __forceinline__ bf16x8 frag(const unsigned char* plane_, int row0, int kc, int lane) { return pw_frag_mc(plane_, row0, kc, lane); }
+};
+
+// ---- convolution gathers (same index algebra as the register loaders in gemm_loaders.h, DMA lane map) -------------------------
+// K-contiguous images: a lane serves LDS row r_j = 32*wave + 16*j + lane/4 (j = 0, 1) and the 8 channels kq8.. of the K-tile.
+
+// fprop A operand: idx = (n,ho,wo), k = (r,s,c) -> x[n][ho*st-pad+r][wo*st-pad+s][c]; C % BK == 0 (a K-tile inside one tap)
+struct DmaConvIm2colKC {
+  static constexpr bool KC = true;
+  struct P { const unsigned short* x; ConvGeom g; int rows; int K; long plane; };
+  const unsigned short* bp; long plane; unsigned off[2], inv[2]; int kq8, W, C, S, wave;
+  int tr, ts, tc, knext;
+  __device__ __forceinline__ void init(const P& p, int idx0, int wave_, int lane) {
+    wave = wave_; plane = p.plane; W = p.g.W; C = p.g.C; S = p.g.S;
+    const int H = p.g.H;
+    kq8 = 8 * ((lane & 3) ^ ((lane >> 4) & 3));
+    const int HoWo = p.g.Ho * p.g.Wo;
+    const int n_first = idx0 / HoWo;
+    const int bias = (p.g.pad * W + p.g.pad) * C;   // keeps off >= 0: the halo reaches `pad` rows / columns before the image
+    bp = p.x + (long)n_first * H * W * C - bias;
+    knext = -1; tr = ts = tc = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = idx0 + 32 * wave + 16 * j + (lane >> 2);
+      const bool in = row < p.rows;
+      const int rowc = in ? row : 0;
+      const int wo = rowc % p.g.Wo; const int t = rowc / p.g.Wo; const int ho = t % p.g.Ho; const int n = t / p.g.Ho;
+      const int h0 = ho * p.g.stride - p.g.pad, w0 = wo * p.g.stride - p.g.pad;
+      off[j] = in ? (unsigned)(((((n - n_first) * H + h0) * W + w0) * C + bias + kq8) * 2) : 0u;
+      inv[j] = in ? tap_mask(outside_bits(-h0, H - h0, p.g.R), outside_bits(-w0, W - w0, S), p.g.R, S) : 0xffffffffu;
+    }
+  }
+  __device__ __forceinline__ void issue(int k0, unsigned char* lds_hi, bool live) {
+    if (k0 != knext) { const int tap = k0 / C; tc = k0 - tap * C; tr = tap / S; ts = tap - tr * S; }
+    const int t = tr * S + ts;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + pl * plane + ((long)(tr * W + ts) * C + tc), live);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) dma16(rs, lds_hi + pl * PW_PLANE + (32 * wave + 16 * j) * 64, masked_off(off[j], inv[j], t));
+    }
+    tc += BK;
+    if (tc >= C) { tc = 0; if (++ts == S) { ts = 0; ++tr; } }
+    knext = k0 + BK;
+  }
+  static __device__ __forceinline__ bf16x8 frag(const unsigned char* plane_, int row0, int kc, int lane) { return pw_frag_kc(plane_, row0, kc, lane); }
+};
+
+// dgrad A operand (stride 1): idx = (n,hi,wi), k = (r,s,ko) -> dy[n][hi+pad-r][wi+pad-s][ko]; Ko % BK == 0
+struct DmaConvDgradKC {
+  static constexpr bool KC = true;
+  struct P { const unsigned short* dy; ConvGeom g; int rows; int K; long plane; };
+  const unsigned short* bp; long plane; unsigned off[2], inv[2]; int kq8, Wo, Ko, R, S, wave;
+  int tr, ts, tk, knext;
+  __device__ __forceinline__ void init(const P& p, int idx0, int wave_, int lane) {
+    wave = wave_; plane = p.plane; Wo = p.g.Wo; Ko = p.g.Ko; R = p.g.R; S = p.g.S;
+    const int Ho = p.g.Ho, H = p.g.H, W = p.g.W, pad = p.g.pad;
+    kq8 = 8 * ((lane & 3) ^ ((lane >> 4) & 3));
+    const int n_first = idx0 / (H * W);
+    bp = p.dy + ((long)n_first * Ho * Wo - ((R - 1) * Wo + (S - 1))) * Ko;
+    knext = -1; tr = ts = tk = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = idx0 + 32 * wave + 16 * j + (lane >> 2);
+      if (row < p.rows) {
+        const int wi = row % W; const int t = row / W; const int hi = t % H; const int n = t / H;
+        off[j] = (unsigned)(((((n - n_first) * Ho + hi + pad) * Wo + wi + pad) * Ko + kq8) * 2);
+        inv[j] = tap_mask(outside_bits(hi + pad - Ho + 1, hi + pad + 1, R), outside_bits(wi + pad - Wo + 1, wi + pad + 1, S), R, S);
+      } else { off[j] = 0; inv[j] = 0xffffffffu; }
+    }
+  }
+  __device__ __forceinline__ void issue(int k0, unsigned char* lds_hi, bool live) {
+    if (k0 != knext) { const int tap = k0 / Ko; tk = k0 - tap * Ko; tr = tap / S; ts = tap - tr * S; }
+    const int t = tr * S + ts;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + pl * plane + ((long)((R - 1 - tr) * Wo + (S - 1 - ts)) * Ko + tk), live);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) dma16(rs, lds_hi + pl * PW_PLANE + (32 * wave + 16 * j) * 64, masked_off(off[j], inv[j], t));
+    }
+    tk += BK;
+    if (tk >= Ko) { tk = 0; if (++ts == S) { ts = 0; ++tr; } }
+    knext = k0 + BK;
+  }
+  static __device__ __forceinline__ bf16x8 frag(const unsigned char* plane_, int row0, int kc, int lane) { return pw_frag_kc(plane_, row0, kc, lane); }
+};
+
+// stride-2 dgrad A operand, one output-parity class: idx = (n,a,b) on the half-resolution grid, k = (ti,ko)
+struct DmaConvDgradS2KC {
+  static constexpr bool KC = true;
+  struct P { const unsigned short* dy; ConvGeom g; S2Taps t; int Hs, Ws; int rows; int K; long plane; };
+  const unsigned short* bp; long plane; unsigned off[2], inv[2]; int kq8, Wo, Ko, wave; S2Taps t;
+  int ti, tk, knext;
+  __device__ __forceinline__ void init(const P& p, int idx0, int wave_, int lane) {
+    wave = wave_; plane = p.plane; Wo = p.g.Wo; Ko = p.g.Ko; t = p.t;
+    const int Ho = p.g.Ho;
+    kq8 = 8 * ((lane & 3) ^ ((lane >> 4) & 3));
+    const int n_first = idx0 / (p.Hs * p.Ws);
+    bp = p.dy + (long)n_first * Ho * Wo * Ko;
+    knext = -1; ti = tk = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = idx0 + 32 * wave + 16 * j + (lane >> 2);
+      if (row < p.rows) {
+        const int b = row % p.Ws; const int q = row / p.Ws; const int a = q % p.Hs; const int n = q / p.Hs;
+        off[j] = (unsigned)(((((n - n_first) * Ho + a) * Wo + b) * Ko + kq8) * 2);
+        unsigned m = 0;
+#pragma unroll
+        for (int ir = 0; ir < 2; ++ir)
+#pragma unroll
+          for (int is = 0; is < 2; ++is)
+            if (ir < t.nr && is < t.ns && (a + t.dr[ir] >= Ho || b + t.ds[is] >= Wo)) m |= 1u << (ir * t.ns + is);
+        inv[j] = m;
+      } else { off[j] = 0; inv[j] = 0xffffffffu; }
+    }
+  }
+  __device__ __forceinline__ void issue(int k0, unsigned char* lds_hi, bool live) {
+    if (k0 != knext) { ti = k0 / Ko; tk = k0 - ti * Ko; }
+    const int ir = ti / t.ns, is = ti - ir * t.ns;
+    const int dr = ir == 0 ? t.dr[0] : t.dr[1], ds = is == 0 ? t.ds[0] : t.ds[1];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + pl * plane + ((long)(dr * Wo + ds) * Ko + tk), live);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) dma16(rs, lds_hi + pl * PW_PLANE + (32 * wave + 16 * j) * 64, masked_off(off[j], inv[j], ti));
+    }
+    tk += BK;
+    if (tk >= Ko) { tk = 0; ++ti; }
+    knext = k0 + BK;
+  }
+  static __device__ __forceinline__ bf16x8 frag(const unsigned char* plane_, int row0, int kc, int lane) { return pw_frag_kc(plane_, row0, kc, lane); }
+};
+
+// idx-contiguous images: a lane serves k-row kl_j = 4*wave + 2*j + lane/32 and the 8 idx at LDS bytes 16*(lane%32), i.e. the
+// logical columns (16*(lane%32) ^ ((kl & 3) << 6)) / 2 .. +7 of the tile.
+
+// dgrad B operand: k = (r,s,ko), idx = c -> w[ko][r][s][c]
+struct DmaConvFilterMC {
+  static constexpr bool KC = false;
+  struct P { const unsigned short* w; ConvGeom g; int cols; int K; long plane; };
+  const unsigned short* bp; long plane, RSC; unsigned voff[2]; int Ko, C, wave;
+  int tap, tk, knext;
+  __device__ __forceinline__ void init(const P& p, int idx0, int wave_, int lane) {
+    wave = wave_; plane = p.plane; Ko = p.g.Ko; C = p.g.C; RSC = (long)p.g.R * p.g.S * p.g.C;
+    bp = p.w + idx0;
+    knext = -1; tap = tk = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kl = 4 * wave + 2 * j + (lane >> 5);
+      const int colb = (16 * (lane & 31)) ^ ((kl & 3) << 6);
+      voff[j] = idx0 + colb / 2 < p.cols ? (unsigned)(kl * (int)RSC * 2 + colb) : VOFF_OOB;
+    }
+  }
+  __device__ __forceinline__ void issue(int k0, unsigned char* lds_hi, bool live) {
+    if (k0 != knext) { tap = k0 / Ko; tk = k0 - tap * Ko; }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + pl * plane + ((long)tk * RSC + (long)tap * C), live);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) dma16(rs, lds_hi + pl * PW_PLANE + (4 * wave + 2 * j) * 512, voff[j]);
+    }
+    tk += BK;
+    if (tk >= Ko) { tk = 0; ++tap; }
+    knext = k0 + BK;
+  }
+  static __device__ __forceinline__ bf16x8 frag(const unsigned char* plane_, int row0, int kc, int lane) { return pw_frag_mc(plane_, row0, kc, lane); }
+};
+
+struct DmaConvFilterS2MC {
+  static constexpr bool KC = false;
+  struct P { const unsigned short* w; ConvGeom g; S2Taps t; int cols; int K; long plane; };
+  const unsigned short* bp; long plane, RSC; unsigned voff[2]; int Ko, C, S, wave; S2Taps t;
+  int ti, tk, knext;
+  __device__ __forceinline__ void init(const P& p, int idx0, int wave_, int lane) {
+    wave = wave_; plane = p.plane; Ko = p.g.Ko; C = p.g.C; S = p.g.S; RSC = (long)p.g.R * p.g.S * p.g.C; t = p.t;
+    bp = p.w + idx0;
+    knext = -1; ti = tk = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kl = 4 * wave + 2 * j + (lane >> 5);
+      const int colb = (16 * (lane & 31)) ^ ((kl & 3) << 6);
+      voff[j] = idx0 + colb / 2 < p.cols ? (unsigned)(kl * (int)RSC * 2 + colb) : VOFF_OOB;
+    }
+  }
+  __device__ __forceinline__ void issue(int k0, unsigned char* lds_hi, bool live) {
+    if (k0 != knext) { ti = k0 / Ko; tk = k0 - ti * Ko; }
+    const int ir = ti / t.ns, is = ti - ir * t.ns;
+    const int tap = (ir == 0 ? t.r[0] : t.r[1]) * S + (is == 0 ? t.s[0] : t.s[1]);
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const __amdgpu_buffer_rsrc_t rs = tile_rsrc(bp + pl * plane + ((long)tk * RSC + (long)tap * C), live);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) dma16(rs, lds_hi + pl * PW_PLANE + (4 * wave + 2 * j) * 512, voff[j]);
+    }
+    tk += BK;
+    if (tk >= Ko) { tk = 0; ++ti; }
+    knext = k0 + BK;
+  }
+  static __device__ __forceinline__ bf16x8 frag(const unsigned char* plane_, int row0, int kc, int lane) { return pw_frag_mc(plane_, row0, kc, lane); }
+};
+
+// wgrad B operand: k = (n,ho,wo), idx = (r,s,c) -> x[n][ho*st-pad+r][wo*st-pad+s][c]   (see ConvIm2colMC in gemm_loaders.h)
+struct DmaConvIm2colMC {
+  static constexpr bool KC = false;
+  struct P { const unsigned short* x; ConvGeom g; int cols; int K; long plane; };
+  const unsigned short* x; long plane; int K, H, W, C, Ho, Wo, st, bias, wave; bool linear, halo;
+  unsigned voff[2]; int kl[2];
+  int dhj[2], dwj[2], ccv[2]; bool okv[2];     // (r - pad, s - pad, c) and column validity of each piece (the two pieces differ)
+  int pn[2], pho[2], pwo[2];                   // pixel (image, row, column) of each piece's k-row in K-tile `knext`
+  int stepq, stepr, un, urem, knext;
+  __device__ __forceinline__ void init(const P& p, int idx0, int wave_, int lane) {
+    wave = wave_; plane = p.plane; K = p.K; x = p.x; H = p.g.H; W = p.g.W; C = p.g.C; Ho = p.g.Ho; Wo = p.g.Wo; st = p.g.stride;
+    // the 8 idx of a lane share (r,s) and are 8 consecutive channels (C % 8 == 0); the XOR moves whole 64-byte groups
+    linear = (st == 1 && Ho == H && Wo == W);
+    halo = (p.g.R * p.g.S > 1) || p.g.pad != 0;
+    stepq = BK / Wo; stepr = BK - stepq * Wo;
+    knext = -1; un = urem = 0;
+    bias = (p.g.pad * W + p.g.pad) * C;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      kl[j] = 4 * wave + 2 * j + (lane >> 5);
+      const int colb = (16 * (lane & 31)) ^ ((kl[j] & 3) << 6);
+      const int col = idx0 + colb / 2;
+      const bool okj = col < p.cols;
+      const int tap = col / C, ccj = col - tap * C;
+      const int r = tap / p.g.S, s = tap - r * p.g.S;
+      dhj[j] = r - p.g.pad; dwj[j] = s - p.g.pad; ccv[j] = ccj; okv[j] = okj;
+      voff[j] = okj ? (unsigned)(((kl[j] + dhj[j] * W + dwj[j]) * C + ccj + bias) * 2) : VOFF_OOB;
+      pn[j] = pho[j] = pwo[j] = 0;
+    }
+  }
+  __device__ __forceinline__ void seek(int k0) {
+    const int HoWo = Ho * Wo;
+    un = k0 / HoWo; urem = k0 - un * HoWo;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + kl[j];
+      pwo[j] = k % Wo; const int t = k / Wo; pho[j] = t % Ho; pn[j] = t / Ho;
+    }
+  }
+  __device__ __forceinline__ void issue(int k0, unsigned char* lds_hi, bool live) {
+    if (k0 != knext) seek(k0);
+    const bool tail = k0 + BK > K;
+    unsigned o[2];
+    if (linear) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        o[j] = voff[j];
+        if (halo || tail) {
+          bool valid = !halo || (((unsigned)(pho[j] + dhj[j]) < (unsigned)H) && ((unsigned)(pwo[j] + dwj[j]) < (unsigned)W));
+          if (tail) valid = valid && (k0 + kl[j] < K);
+          if (!valid) o[j] = VOFF_OOB;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int hi = pho[j] * st + dhj[j], wi = pwo[j] * st + dwj[j];
+        bool valid = okv[j] && ((unsigned)hi < (unsigned)H) && ((unsigned)wi < (unsigned)W);
+        if (tail) valid = valid && (k0 + kl[j] < K);
+        o[j] = valid ? (unsigned)(((((pn[j] - un) * H + hi) * W + wi) * C + ccv[j]) * 2) : VOFF_OOB;
+      }
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const __amdgpu_buffer_rsrc_t rs = linear ? tile_rsrc(x + pl * plane + ((long)k0 * C - bias), live) : tile_rsrc(x + pl * plane + (long)un * H * W * C, live);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) dma16(rs, lds_hi + pl * PW_PLANE + (4 * wave + 2 * j) * 512, o[j]);
+    }
+    if (halo || !linear) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int wo = pwo[j] + stepr, ho = pho[j] + stepq;
+        if (wo >= Wo) { wo -= Wo; ++ho; }
+        int n = pn[j];
+        while (ho >= Ho) { ho -= Ho; ++n; }
+        pwo[j] = wo; pho[j] = ho; pn[j] = n;
+      }
+      urem += BK;
+      const int HoWo = Ho * Wo;
+      while (urem >= HoWo) { urem -= HoWo; ++un; }
+    }
+    knext = k0 + BK;
+  }
+  static __device__ __forceinline__ bf16x8 frag(const unsigned char* plane_, int row0, int kc, int lane) { return pw_frag_mc(plane_, row0, kc, lane); }
+};
+
+// ---- kernel -----------------------------------------------------------------------------------------------------------
+struct PwFragA { bf16x8 h[2], l[2]; };   // two 32-row blocks of the A operand, hi / lo
+struct PwFragB { bf16x8 h[2], l[2]; };   // the wave's two 32-column blocks of the B operand
+
+template <class LA>
+__device__ __forceinline__ void pw_read_a(PwFragA& f, const unsigned char* st, int wm, int ib, int kc, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    f.h[i] = LA::frag(st, wm * 128 + (ib + i) * 32, kc, lane);
+    f.l[i] = LA::frag(st + PW_PLANE, wm * 128 + (ib + i) * 32, kc, lane);
+  }
+}
+template <class LB>
+__device__ __forceinline__ void pw_read_b(PwFragB& f, const unsigned char* st, int wn, int kc, int lane) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    f.h[j] = LB::frag(st + 2 * PW_PLANE, wn * 64 + j * 32, kc, lane);
+    f.l[j] = LB::frag(st + 3 * PW_PLANE, wn * 64 + j * 32, kc, lane);
+  }
+}
+__device__ __forceinline__ void pw_mfma12(f32x16 (&acc)[2][2], const PwFragA& a, const PwFragB& b) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[i], b.h[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[i], b.l[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[i], b.h[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+#ifndef CXRK_PW_SCHED
+#define CXRK_PW_SCHED 1   // 1: pin the group boundaries (reads of group g+1 stay in front of the MFMAs of group g)
+#endif
+#define PW_FENCE() do { if (CXRK_PW_SCHED) __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <class LA, class LB>
+__global__ __launch_bounds__(PW_NT, 1) void gemm_pw_kernel(typename LA::P pa, typename LB::P pb, EpiParams ep, int M, int N, int K,
+                                                           int nMt, int nNt, int kchunk) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * PW_STAGE];
+  int mt, nt;
+  tile_coords(nMt, nNt, mt, nt);
+  const int m0 = mt * 256, n0 = nt * 256;
+  const int z = blockIdx.y;
+  const int kbeg = z * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+#define PW_STAMP(i) do { if (ep.stamps && tid == 0) { ep.stamps[(blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+                            if ((i) == 0 || (i) == 4) ep.stamps[(blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 + 5 + (i) / 4] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+  PW_STAMP(0);
+  LA la; LB lb;
+  la.init(pa, m0, wave, lane);
+  lb.init(pb, n0, wave, lane);
+
+  f32x16 acc0[2][2], acc1[2][2];   // rows 0-63 / 64-127 of the wave's 128 x 64 outputs
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
+
+  la.issue(kbeg, smem, kbeg < kend);
+  lb.issue(kbeg, smem + 2 * PW_PLANE, kbeg < kend);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  PW_STAMP(1);
+  PwFragA A0, A1; PwFragB B0, B1;
+  pw_read_a<LA>(A0, smem, wm, 0, 0, lane);
+  pw_read_b<LB>(B0, smem, wn, 0, lane);
+
+  int cur = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const unsigned char* st = smem + cur * PW_STAGE;
+    unsigned char* nx = smem + (cur ^ 1) * PW_STAGE;
+    const bool more = k0 + BK < kend;
+    // group 0: rows 0-63, k-step 0
+    pw_read_a<LA>(A1, st, wm, 2, 0, lane);
+    la.issue(k0 + BK, nx, more);
+    PW_FENCE();
+    pw_mfma12(acc0, A0, B0);
+    PW_FENCE();
+    // group 1: rows 64-127, k-step 0
+    pw_read_a<LA>(A0, st, wm, 0, 1, lane);
+    pw_read_b<LB>(B1, st, wn, 1, lane);
+    lb.issue(k0 + BK, nx + 2 * PW_PLANE, more);
+    PW_FENCE();
+    pw_mfma12(acc1, A1, B0);
+    PW_FENCE();
+    // group 2: rows 0-63, k-step 1
+    pw_read_a<LA>(A1, st, wm, 2, 1, lane);
+    PW_FENCE();
+    pw_mfma12(acc0, A0, B1);
+    PW_FENCE();
+    // group 3: rows 64-127, k-step 1 — behind the K-tile's one barrier (see the hazard notes in the header comment)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    pw_read_a<LA>(A0, nx, wm, 0, 0, lane);
+    pw_read_b<LB>(B0, nx, wn, 0, lane);
+    PW_FENCE();
+    pw_mfma12(acc1, A1, B1);
+    PW_FENCE();
+    cur ^= 1;
+  }
+  PW_STAMP(2);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();   // every wave is done with the operand buffers: they become the epilogue's transpose staging
+  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+  // planes operands are always 16-byte aligned (launch_gemm_pw refuses anything else): the fast epilogue only
+  epi64_dispatch<0>(ep.kind, acc0, ep, stg, M, N, m0 + wm * 128, n0 + wn * 64, mt * 4 + wm * 2, z, lane);
+  epi64_dispatch<0>(ep.kind, acc1, ep, stg, M, N, m0 + wm * 128 + 64, n0 + wn * 64, mt * 4 + wm * 2 + 1, z, lane);
+  PW_STAMP(3);
+  if (ep.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PW_STAMP(4); }
+#undef PW_STAMP
+}
+
+template <class LA, class LB>
+static int launch_gemm_pw(const typename LA::P& pa, const typename LB::P& pb, const EpiParams& ep, int M, int N, int K, int splitk,
+                          hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return CXRK_ERR_ARG;
+  const int nMt = ceil_div(M, 256), nNt = ceil_div(N, 256);
+  int kchunk = K;
+  if (splitk > 1) { kchunk = ceil_div(ceil_div(K, splitk), BK) * BK; splitk = ceil_div(K, kchunk); }
+  else splitk = 1;
+  dim3 grid((unsigned)(nMt * nNt), (unsigned)splitk, 1);
+  EpiParams e = ep;
+  if (!prep_epilogue(e, M, N, splitk) || !e.fast) return CXRK_ERR_ARG;
+  hipLaunchKernelGGL((gemm_pw_kernel<LA, LB>), grid, dim3(PW_NT), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
+  CXRK_LAUNCH_CHECK();
+  return splitk;
+}
+
+}  // namespace cxrk

@@ -153,6 +153,22 @@ class ImageModel(nn.Module):
         return emb
 
     @torch.no_grad()
+    def project_patch_embeddings(self, patch_embeddings: torch.Tensor) -> torch.Tensor:
+        """The projector alone (reference `modules.MLP`, modules.py:29-47): trunk patch embeddings [B,2048,h,w] ->
+        projected patch embeddings [B,joint,h,w]."""
+        self._check_mode()
+        params, bufs = self._tensors()
+        return IE.project_patches(self._specs, params, bufs, patch_embeddings)
+
+    @torch.no_grad()
+    def forward_stages(self, x: torch.Tensor):
+        """Diagnostic: [max-pooled stem, layer1..layer4] outputs (fp32 NCHW) from the kernels `forward` runs."""
+        self._check_mode()
+        self.prepare_()
+        params, bufs = self._tensors()
+        return IE.forward_stages(self._specs, self._blocks, params, bufs, x)
+
+    @torch.no_grad()
     def get_patchwise_projected_embeddings(self, input_img: torch.Tensor, normalize: bool) -> torch.Tensor:
         """Patch-wise projected embeddings [batch, n_patches_h, n_patches_w, feature_size] (`model.py:161-173`)."""
         assert not self.training, "This function is only implemented for evaluation mode"

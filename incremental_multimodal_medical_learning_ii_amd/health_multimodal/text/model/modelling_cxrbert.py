@@ -92,7 +92,7 @@ class CXRBertModel(BertForMaskedLM):
             raise NotImplementedError("CXRBertModel is in training mode with dropout > 0, which the HIP path does not implement; "
                                       "call .eval() (parameters still receive gradients) or set the dropout probabilities to 0")
 
-    def _encode(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], cls_only: bool = False):
+    def _encode(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], cls_only: bool = False, want_last: bool = True):
         if not input_ids.is_cuda:
             raise RuntimeError("CXRBertModel runs on the MI355X only: move the model and inputs to 'cuda' "
                                "(there is no CPU fallback; the CPU oracle lives in oracle/ and is test-only)")
@@ -102,7 +102,7 @@ class CXRBertModel(BertForMaskedLM):
         if getattr(cfg, "hidden_act", "gelu") != "gelu":
             raise NotImplementedError(f"hidden_act={cfg.hidden_act!r}: only erf-GELU (CXR-BERT) is implemented")
         return TE.encode(self._hot_params(), input_ids, attention_mask, cfg.num_hidden_layers,
-                         cfg.num_attention_heads, cfg.layer_norm_eps, cls_only)
+                         cfg.num_attention_heads, cfg.layer_norm_eps, cls_only, want_last)
 
     @torch.no_grad()
     def _mlm_logits(self, last_hidden: torch.Tensor) -> torch.Tensor:
@@ -156,7 +156,7 @@ class CXRBertModel(BertForMaskedLM):
         (reference `modelling_cxrbert.py:117-141`)."""
         # Only hidden_states[-1][:, 0, :] feeds the projection head (:98-99): the last layer's row-wise part runs on the CLS
         # rows alone (text_encoder._forward, cls_only).  Same values as forward(...).cls_projected_embedding.
-        cls_projected_embedding, _ = self._encode(input_ids, attention_mask, cls_only=True)
+        cls_projected_embedding, _ = self._encode(input_ids, attention_mask, cls_only=True, want_last=False)
         if normalize_embeddings:
             from ....functional import l2_normalize
             return l2_normalize(cls_projected_embedding)

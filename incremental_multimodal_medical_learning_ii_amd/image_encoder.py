@@ -8,18 +8,35 @@ torchvision 0.10 `Bottleneck` (1x1 -> 3x3(stride) -> 1x1, BN after each, residua
 encoder in (`chexpert-get-embedding.py:41-42`) — but gamma/beta (and every conv weight) still receive gradients:
 
     y = conv(x, w)*s + t,  s = gamma*rsqrt(var+eps),  t = beta - mean*s
-    dx = conv^T(dy, w*s);  dw = s * wgrad(x, dy);  dbeta = sum(dy);  dgamma = sum(dy * (y_bn - beta)) / gamma
+    dx = conv^T(dy, w*s);  dw = s * wgrad(x, dy);  dbeta = sum(dy);  dgamma = rstd * (<w, wgrad(x, dy)> - mean*sum(dy))
+
+(dgamma = sum dy*xhat written through the raw weight gradient: nothing of the forward has to be re-read for it and gamma is
+never divided by; measured against the direct sum on this network: < 1e-6 of the tensor maximum, scripts/exp_dgamma.py.)
 
 Working layout: activations NHWC, filters [Ko][R][S][C] (the parameters are kept in torch `channels_last` memory
 format, so state-dict shapes stay OIHW).  The stem's 3 input channels are zero-padded to 4 (16-byte loads).
+
+Two storage modes, chosen by the library's contraction precision (`_lib.get_precision()`):
+  fp32        activations, folded filters and gradients are fp32 tensors; ReLU masks are taken from the sign of the saved
+              activation (exact-fp32 MFMA mainloop).
+  split_bf16  every activation / gradient / folded filter that feeds a contraction is a `kernels.Planes` tensor (bf16 hi + lo
+              planes, 4 bytes per element) written by the producing kernel's epilogue, so the MFMA mainloops load operands with
+              no conversion work; ReLU decisions are saved as bit masks (1 bit per element) by the forward epilogues and read
+              by the data-gradient epilogues.  The stem reads the fp32 image (fp32 gather, split on the fly) and its weight
+              gradient stays exact fp32 (an all-positive input makes it a cancelling sum).
+Parameter gradients are written (accumulated) straight into `param.grad` when that exists with the parameter's own memory
+layout — the flat gradient buffer of `optim._FlatOptimizer` — so autograd has nothing to add afterwards.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
+from . import _lib
 from . import kernels as K
+from .gradsink import GradSink
+from .kernels import Planes
 
 LAYERS = (3, 4, 6, 3)
 PLANES = (64, 128, 256, 512)
@@ -73,24 +90,39 @@ def buffer_names(specs: Sequence[ConvSpec]) -> List[str]:
     return names
 
 
-class _Fold:
-    """Per-forward folded filters and BN vectors (one flat buffer each)."""
+def _planes_mode() -> bool:
+    return _lib.get_precision() == "split_bf16"
 
-    def __init__(self, specs: Sequence[ConvSpec], device):
-        tot_w = sum(s.cout * s.k * s.k * s.cpad for s in specs)
+
+class _Fold:
+    """Per-forward folded filters and BN vectors (one flat buffer each).  In planes mode the folded filters of every unit but
+    the stem live in ONE [2, total] bf16 buffer (unit i = a column slice of both planes)."""
+
+    def __init__(self, specs: Sequence[ConvSpec], device, pl: bool):
+        self.pl = pl
+        sizes = [s.cout * s.k * s.k * s.cpad for s in specs]
         tot_c = sum(s.cout for s in specs)
-        self.w = torch.empty(tot_w, dtype=torch.float32, device=device)
         self.vec = torch.empty(3, tot_c, dtype=torch.float32, device=device)
         self.woff, self.coff = [], []
         a = b = 0
-        for s in specs:
+        for s, n in zip(specs, sizes):
             self.woff.append(a)
             self.coff.append(b)
-            a += s.cout * s.k * s.k * s.cpad
+            a += (n + 7) // 8 * 8
             b += s.cout
+        self.sizes = sizes
+        if pl:
+            self.wp = torch.empty(2, a, dtype=torch.bfloat16, device=device)
+            self.w = torch.empty(sizes[0], dtype=torch.float32, device=device)    # the stem's filters stay fp32
+        else:
+            self.w = torch.empty(a, dtype=torch.float32, device=device)
 
     def ws(self, i, s):
-        return self.w[self.woff[i]: self.woff[i] + s.cout * s.k * s.k * s.cpad]
+        """folded filter of unit i: fp32 [Ko*R*S*cpad] (fp32 mode, and the stem always) or Planes [Ko, R*S*cpad]"""
+        n = self.sizes[i]
+        if self.pl and i > 0:
+            return Planes(self.wp[:, self.woff[i]: self.woff[i] + n].view(2, s.cout, n // s.cout))
+        return self.w[:n] if self.pl else self.w[self.woff[i]: self.woff[i] + n]
 
     def scale(self, i, s):
         return self.vec[0, self.coff[i]: self.coff[i] + s.cout]
@@ -108,158 +140,239 @@ def _filter_rsc(w: torch.Tensor) -> torch.Tensor:
     return v if v.is_contiguous() else v.contiguous()
 
 
-def _conv(i, s, fold, x, residual, relu, N, H, W):
-    Ho = (H + 2 * s.pad - s.k) // s.stride + 1
-    Wo = (W + 2 * s.pad - s.k) // s.stride + 1
-    y = torch.empty(N, Ho, Wo, s.cout, dtype=torch.float32, device=x.device)
-    K.conv_fwd(x, fold.ws(i, s), fold.shift(i, s), residual, y, N, H, W, s.cpad, s.cout, s.k, s.k, s.stride, s.pad, relu)
-    return y
+def _out_hw(s, H, W):
+    return (H + 2 * s.pad - s.k) // s.stride + 1, (W + 2 * s.pad - s.k) // s.stride + 1
+
+
+def _conv(i, s, fold, x, residual, relu, N, H, W, pl, want_mask=True):
+    """unit i forward -> (y, mask).  planes mode: y Planes, mask = ReLU decision bits (uint8 [N*Ho*Wo, Ko/8]) when relu;
+    fp32 mode: y fp32, mask None (the backward reads the sign of y)."""
+    Ho, Wo = _out_hw(s, H, W)
+    dev = fold.vec.device
+    if not pl:
+        y = torch.empty(N, Ho, Wo, s.cout, dtype=torch.float32, device=dev)
+        K.conv_fwd(x, fold.ws(i, s), fold.shift(i, s), residual, y, N, H, W, s.cpad, s.cout, s.k, s.k, s.stride, s.pad, relu)
+        return y, None
+    y = Planes.empty(N, Ho, Wo, s.cout, device=dev)
+    mask = torch.empty(N * Ho * Wo, s.cout // 8, dtype=torch.uint8, device=dev) if (relu and want_mask) else None
+    K.conv_fwd_pl(x, fold.ws(i, s), fold.shift(i, s), residual, y, mask, N, H, W, s.cpad, s.cout, s.k, s.k, s.stride, s.pad, relu)
+    return y, mask
 
 
 def _forward(specs, blocks, p: Sequence[torch.Tensor], bufs: Sequence[torch.Tensor], x: torch.Tensor, save: bool,
-             want_patch: bool):
+             want_patch: bool, stages: Optional[list] = None, keep_stem: bool = False):
     N, C, H, W = x.shape
     if C != 3:
         raise ValueError(f"ImageModel expects 3-channel input (ExpandChannels, transforms.py:12-38), got {C}")
     dev = x.device
-    fold = _Fold(specs, dev)
+    pl = _planes_mode()
+    fold = _Fold(specs, dev, pl)
     for i, s in enumerate(specs):
-        K.bn_fold(_filter_rsc(p[3 * i]), p[3 * i + 1], p[3 * i + 2], bufs[2 * i], bufs[2 * i + 1], BN_EPS, s.cout, s.k * s.k,
-                  s.cin, s.cpad, fold.ws(i, s), fold.scale(i, s), fold.shift(i, s), fold.rstd(i, s))
-    acts: Dict[str, torch.Tensor] = {}
+        args = (_filter_rsc(p[3 * i]), p[3 * i + 1], p[3 * i + 2], bufs[2 * i], bufs[2 * i + 1], BN_EPS, s.cout, s.k * s.k, s.cin, s.cpad)
+        if pl and i > 0:
+            K.bn_fold_pl(*args, fold.ws(i, s), fold.scale(i, s), fold.shift(i, s), fold.rstd(i, s))
+        else:
+            K.bn_fold(*args, fold.ws(i, s), fold.scale(i, s), fold.shift(i, s), fold.rstd(i, s))
     x0 = K.nchw_to_nhwc(x, 4)
-    stem = _conv(0, specs[0], fold, x0, None, True, N, H, W)
-    pooled, idx = K.maxpool_fwd(stem)
+    stem, _ = _conv(0, specs[0], fold, x0, None, True, N, H, W, pl, want_mask=False)   # its ReLU mask = sign of the pooled value
+    Hs, Ws = stem.shape[1], stem.shape[2]
+    pooled, idx = K.maxpool_fwd_pl(stem) if pl else K.maxpool_fwd(stem)
+    if pl and not keep_stem:
+        stem = None                       # planes mode: the max-pool backward needs only `pooled`
     cur = pooled
     h, w = cur.shape[1], cur.shape[2]
+    if stages is not None:
+        stages.append(cur)
     binfo = []
-    for blk in blocks:
+    for bi, blk in enumerate(blocks):
         s1, s2, s3 = specs[blk["c1"]], specs[blk["c2"]], specs[blk["c3"]]
-        o1 = _conv(blk["c1"], s1, fold, cur, None, True, N, h, w)
-        o2 = _conv(blk["c2"], s2, fold, o1, None, True, N, h, w)
+        o1, m1 = _conv(blk["c1"], s1, fold, cur, None, True, N, h, w, pl)
+        o2, m2 = _conv(blk["c2"], s2, fold, o1, None, True, N, h, w, pl)
         h2, w2 = o2.shape[1], o2.shape[2]
         if blk["ds"] is not None:
-            idt = _conv(blk["ds"], specs[blk["ds"]], fold, cur, None, False, N, h, w)
+            idt, _ = _conv(blk["ds"], specs[blk["ds"]], fold, cur, None, False, N, h, w, pl)
         else:
             idt = cur
-        out = _conv(blk["c3"], s3, fold, o2, idt, True, N, h2, w2)
+        out, m3 = _conv(blk["c3"], s3, fold, o2, idt, True, N, h2, w2, pl)
         if save:
-            binfo.append((cur, o1, o2, out, idt if blk["ds"] is not None else None, h, w, h2, w2))
+            # fp32 mode keeps `out` for its sign; planes mode keeps the three bit masks instead (out lives on as the next `cur`)
+            binfo.append((cur, o1, o2, out if not pl else None, h, w, h2, w2, m1, m2, m3))
         cur, h, w = out, h2, w2
+        if stages is not None and (bi + 1 == len(blocks) or blocks[bi + 1]["ds"] is not None):
+            stages.append(cur)
     ip = len(specs) - 1
-    pj1 = _conv(ip, specs[ip], fold, cur, None, True, N, h, w)
+    pj1, mp = _conv(ip, specs[ip], fold, cur, None, True, N, h, w, pl)
     w3, b3 = p[3 * len(specs)], p[3 * len(specs) + 1]
-    pj2 = K.linear_fwd(pj1.view(N * h * w, -1), w3.reshape(w3.shape[0], -1), b3)
+    w3m = w3.reshape(w3.shape[0], -1)
+    if pl:
+        w3p = K.split_planes(w3m)
+        pj2 = K.linear_fwd_pl(pj1.view(N * h * w, pj1.shape[-1]), w3p, b3)
+    else:
+        w3p = None
+        pj2 = K.linear_fwd(pj1.view(N * h * w, -1), w3m, b3)
     emb = K.spatial_mean_fwd(pj2.view(N, h * w, -1))
     patch = pj2.view(N, h, w, -1) if want_patch else None
-    state = (fold, x0, stem, idx, pooled, binfo, cur, pj1, (N, H, W, h, w)) if save else None
+    state = (fold, x0, stem, idx, pooled, binfo, cur, pj1, mp, w3p, (N, H, W, Hs, Ws, h, w), pl) if save else None
     return emb, patch, state
 
 
-def _unit_bwd(i, s, fold, p, bufs, x, dy, y, sub, N, H, W, grads, sums=None):
-    """Parameter gradients of conv+BN unit i.  x: its input [N,H,W,cpad]; dy: masked gradient w.r.t. its BN output;
-    (y - sub) equals the BN output wherever dy != 0 (y = post-ReLU output, sub = the residual that was added).
-    `sums` = (sum dy, sum dy*(y_bn - beta)) when the data-gradient kernel that produced dy already reduced them."""
-    if sums is None:
-        sums = torch.empty(2, s.cout, dtype=torch.float32, device=dy.device)
-        K.bn_bwd_reduce(dy, y, sub, p[3 * i + 2], sums[0], sums[1])
+def _unit_params_bwd(i, s, fold, p, bufs, x, dy, sumdy, N, H, W, sink: GradSink, pl):
+    """Parameter gradients of conv+BN unit i.  x: its input; dy: masked gradient w.r.t. its BN output; sumdy = sum of dy over
+    pixels ([cout], reduced by the kernel that produced dy)."""
     w = _filter_rsc(p[3 * i])
-    dw = torch.empty_like(w)
-    dg, db = torch.empty_like(p[3 * i + 1]), torch.empty_like(p[3 * i + 2])
-    K.conv_bwd_params(x, dy, w, fold.scale(i, s), fold.rstd(i, s), bufs[2 * i], sums[0], p[3 * i + 1], sums[1], dw, dg, db,
-                      False, N, H, W, s.cin, s.cpad, s.cout, s.k, s.k, s.stride, s.pad)
-    grads[3 * i] = dw.permute(0, 3, 1, 2)  # logical OIHW, channels_last strides (matches the parameter)
-    grads[3 * i + 1], grads[3 * i + 2] = dg, db
+    trip = [sink.dst(3 * i + k) for k in range(3)]
+    if len({acc for _, acc in trip}) > 1:          # one accumulate switch per launch: all three direct, or all three fresh
+        trip = [sink.dst(3 * i + k, force_fresh=True) for k in range(3)]
+    (gw, acc), (dg, _), (db, _) = trip
+    if not acc and not gw.permute(0, 2, 3, 1).is_contiguous():     # fresh tensor: give it the filter's [Ko][R][S][C] memory
+        gw = torch.empty_like(w).permute(0, 3, 1, 2)
+        sink.ret[3 * i] = gw
+    dw = gw.permute(0, 2, 3, 1)
+    args = (w, fold.scale(i, s), fold.rstd(i, s), bufs[2 * i], sumdy, dw, dg, db, acc, N, H, W)
+    if pl and i > 0:
+        K.conv_bwd_params_pl(x, dy, *args, s.cpad, s.cout, s.k, s.k, s.stride, s.pad)
+    else:
+        K.conv_bwd_params(x, dy, *args, s.cin, s.cpad, s.cout, s.k, s.k, s.stride, s.pad)
 
 
-def _dgrad(i, s, fold, dy, residual, relu_src, N, H, W, bn=None):
-    """Data gradient of unit i.  bn = (sub, beta, beta2): also reduce, in the same epilogue, the BN-backward channel
-    sums of the unit(s) that produced `relu_src` -> returns (dx, sums[3,C])."""
-    dx = torch.empty(N, H, W, s.cpad, dtype=torch.float32, device=dy.device)
-    if bn is None:
-        K.conv_bwd_data(dy, fold.ws(i, s), residual, relu_src, dx, N, H, W, s.cpad, s.cout, s.k, s.k, s.stride, s.pad)
-        return dx
-    sums = torch.empty(3, s.cpad, dtype=torch.float32, device=dy.device)
-    K.conv_bwd_data_bnsum(dy, fold.ws(i, s), residual, relu_src, dx, N, H, W, s.cpad, s.cout, s.k, s.k, s.stride, s.pad,
-                          bn[0], bn[1], bn[2], sums)
-    return dx, sums
+def _dgrad(i, s, fold, dy, residual, relu, N, H, W, pl, want_sums):
+    """Data gradient of unit i, masked by `relu` (planes mode: the bit mask of the tensor the gradient flows into; fp32 mode:
+    that tensor itself).  want_sums: also the column sums of the result (-> (dx, sums[C]))."""
+    dev = fold.vec.device
+    sums = torch.empty(s.cpad, dtype=torch.float32, device=dev) if want_sums else None
+    if pl:
+        dx = Planes.empty(N, H, W, s.cpad, device=dev)
+        K.conv_bwd_data_pl(dy, fold.ws(i, s), residual, relu, dx, N, H, W, s.cpad, s.cout, s.k, s.k, s.stride, s.pad, sums)
+    else:
+        dx = torch.empty(N, H, W, s.cpad, dtype=torch.float32, device=dev)
+        K.conv_bwd_data(dy, fold.ws(i, s), residual, relu, dx, N, H, W, s.cpad, s.cout, s.k, s.k, s.stride, s.pad, sums)
+    return (dx, sums) if want_sums else dx
 
 
-def _backward(specs, blocks, p, bufs, state, demb: torch.Tensor, dpatch: Optional[torch.Tensor]):
-    fold, x0, stem, idx, pooled, binfo, last, pj1, (N, H, W, h, w) = state
-    grads: List[Optional[torch.Tensor]] = [None] * len(p)
+def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatch: Optional[torch.Tensor], sink: GradSink):
+    fold, x0, stem, idx, pooled, binfo, last, pj1, mp, w3p, (N, H, W, Hs, Ws, h, w), pl = state
     ns = len(specs)
     ip = ns - 1
     w3 = p[3 * ns]
     w3m = w3.reshape(w3.shape[0], -1)
     J = w3m.shape[0]
-    if demb is not None:
-        dpj2 = K.spatial_mean_bwd(demb.contiguous(), h * w).view(N * h * w, J)
-        if dpatch is not None:
-            dpj2 = dpj2 + dpatch.reshape(N * h * w, J)
+    dev = w3.device
+    P = h * w
+    # ---- projector head: pj2 = pj1 @ w3^T + b3, emb = mean over the P patches
+    gw3, acc3 = sink.dst(3 * ns)
+    gb3, accb3 = sink.dst(3 * ns + 1)
+    gw3m = gw3.permute(0, 2, 3, 1).reshape(J, -1) if gw3.dim() == 4 else gw3.reshape(J, -1)   # [J, C, 1, 1] is [J, C] in memory
+    assert gw3m.data_ptr() == gw3.data_ptr()
+    if pl:
+        if demb is not None:
+            dpj2 = K.spatial_mean_bwd_pl(demb.contiguous(), P, add=dpatch.reshape(N, P, J) if dpatch is not None else None).view(N * P, J)
+        else:
+            dpj2 = K.split_planes(dpatch.reshape(N * P, J).contiguous())
+        pj1m = pj1.view(N * P, pj1.shape[-1])
+        K.linear_bwd_weight_pl(dpj2, pj1m, gw3m, accumulate=acc3)
+        K.colsum_pl(dpj2, gb3, accumulate=accb3)
+        g = K.linear_bwd_data_pl(dpj2, w3p, maskin=mp, out_planes=True)
+        sum_p = K.colsum_pl(g, torch.empty(g.shape[1], dtype=torch.float32, device=dev))
+        g = g.view(N, h, w, g.shape[1])
     else:
-        dpj2 = dpatch.reshape(N * h * w, J).contiguous()
-    pj1m = pj1.view(N * h * w, -1)
-    grads[3 * ns] = K.linear_bwd_weight(dpj2, pj1m, torch.empty_like(w3m)).view(w3.shape)
-    grads[3 * ns + 1] = K.colsum(dpj2, torch.empty_like(p[3 * ns + 1]))
-    g = K.linear_bwd_data(dpj2, w3m, aux=pj1m, auxmode=K.AUX_RELU_MASK).view(N, h, w, -1)
-    _unit_bwd(ip, specs[ip], fold, p, bufs, last, g, pj1, None, N, h, w, grads)
-
-    def beta(i):
-        return p[3 * i + 2]
-
-    def block_bn(bi):
-        """(sub, beta, beta2) for the gradient w.r.t. block bi's output: its conv3 unit (y_bn = out - identity) and, when
-        the identity is a downsample unit, that unit too (y_bn = identity)."""
-        blk = blocks[bi]
-        idt = binfo[bi][4] if blk["ds"] is not None else binfo[bi][0]
-        return (idt, beta(blk["c3"]), beta(blk["ds"]) if blk["ds"] is not None else None)
+        if demb is not None:
+            dpj2 = K.spatial_mean_bwd(demb.contiguous(), P).view(N * P, J)
+            if dpatch is not None:
+                dpj2 = dpj2 + dpatch.reshape(N * P, J)
+        else:
+            dpj2 = dpatch.reshape(N * P, J).contiguous()
+        pj1m = pj1.view(N * P, -1)
+        K.linear_bwd_weight(dpj2, pj1m, gw3m, accumulate=acc3)
+        K.colsum(dpj2, gb3, accumulate=accb3)
+        g = K.linear_bwd_data(dpj2, w3m, aux=pj1m, auxmode=K.AUX_RELU_MASK)
+        sum_p = K.colsum(g, torch.empty(g.shape[1], dtype=torch.float32, device=dev))
+        g = g.view(N, h, w, -1)
+    _unit_params_bwd(ip, specs[ip], fold, p, bufs, last, g, sum_p, N, h, w, sink, pl)
 
     nb = len(blocks)
-    g, gs = _dgrad(ip, specs[ip], fold, g, None, last, N, h, w, bn=block_bn(nb - 1))
+
+    def relu_of_block_out(bi):
+        """what masks a gradient flowing into block bi's output: its bit mask (planes) or the output itself (fp32)"""
+        return binfo[bi][10] if pl else binfo[bi][3]
+
+    g, gs = _dgrad(ip, specs[ip], fold, g, None, relu_of_block_out(nb - 1), N, h, w, pl, True)
     for bi in reversed(range(nb)):
         blk = blocks[bi]
-        cur, o1, o2, out, idt, hi, wi, h2, w2 = binfo[bi]
+        cur, o1, o2, out, hi, wi, h2, w2, m1, m2, m3 = binfo[bi]
         s1, s2, s3 = specs[blk["c1"]], specs[blk["c2"]], specs[blk["c3"]]
-        # out = relu(bn3(conv3(o2)) + identity): g (already masked by out > 0) is dy of bn3 and of the downsample BN;
-        # their channel sums gs were reduced by the kernel that produced g
-        _unit_bwd(blk["c3"], s3, fold, p, bufs, o2, g, out, idt if idt is not None else cur, N, h2, w2, grads, sums=gs[0:2])
-        d2, q2 = _dgrad(blk["c3"], s3, fold, g, None, o2, N, h2, w2, bn=(None, beta(blk["c2"]), None))
-        _unit_bwd(blk["c2"], s2, fold, p, bufs, o1, d2, o2, None, N, hi, wi, grads, sums=q2[0:2])
-        d1, q1 = _dgrad(blk["c2"], s2, fold, d2, None, o1, N, hi, wi, bn=(None, beta(blk["c1"]), None))
+        # out = relu(bn3(conv3(o2)) + identity): g (already masked by out > 0) is dy of bn3 and of the downsample BN; its
+        # channel sums gs were reduced by the kernel that produced g
+        _unit_params_bwd(blk["c3"], s3, fold, p, bufs, o2, g, gs, N, h2, w2, sink, pl)
+        d2, q2 = _dgrad(blk["c3"], s3, fold, g, None, m2 if pl else o2, N, h2, w2, pl, True)
+        _unit_params_bwd(blk["c2"], s2, fold, p, bufs, o1, d2, q2, N, hi, wi, sink, pl)
+        d1, q1 = _dgrad(blk["c2"], s2, fold, d2, None, m1 if pl else o1, N, hi, wi, pl, True)
         del d2
-        _unit_bwd(blk["c1"], s1, fold, p, bufs, cur, d1, o1, None, N, hi, wi, grads, sums=q1[0:2])
+        _unit_params_bwd(blk["c1"], s1, fold, p, bufs, cur, d1, q1, N, hi, wi, sink, pl)
         if blk["ds"] is not None:
             sd = specs[blk["ds"]]
-            _unit_bwd(blk["ds"], sd, fold, p, bufs, cur, g, idt, None, N, hi, wi, grads, sums=torch.stack([gs[0], gs[2]]))
-            res = _dgrad(blk["ds"], sd, fold, g, None, None, N, hi, wi)
+            _unit_params_bwd(blk["ds"], sd, fold, p, bufs, cur, g, gs, N, hi, wi, sink, pl)
+            res = _dgrad(blk["ds"], sd, fold, g, None, None, N, hi, wi, pl, False)
         else:
             res = g
-        binfo_prev_bn = block_bn(bi - 1) if bi > 0 else None
-        if binfo_prev_bn is not None:
-            g, gs = _dgrad(blk["c1"], s1, fold, d1, res, cur, N, hi, wi, bn=binfo_prev_bn)
-        else:
-            g, gs = _dgrad(blk["c1"], s1, fold, d1, res, cur, N, hi, wi), None
+        if bi > 0:
+            g, gs = _dgrad(blk["c1"], s1, fold, d1, res, relu_of_block_out(bi - 1), N, hi, wi, pl, True)
+        else:   # the block input is the max-pool output: its ReLU (the stem's) is applied by the max-pool backward
+            g, gs = _dgrad(blk["c1"], s1, fold, d1, res, None, N, hi, wi, pl, False), None
         del d1, res
         binfo[bi] = None
-    ds = K.maxpool_bwd(g, idx, stem, True)
-    _unit_bwd(0, specs[0], fold, p, bufs, x0, ds, stem, None, N, H, W, grads)
-    return grads
+    if pl:
+        ds = K.maxpool_bwd_pl(g, idx, pooled, Hs, Ws)
+    else:
+        ds = K.maxpool_bwd(g, idx, stem, True)
+    if _debug is not None:
+        _debug["ds"], _debug["x0"] = ds, x0
+    sum_s = K.colsum(ds.view(-1, ds.shape[-1]), torch.empty(ds.shape[-1], dtype=torch.float32, device=dev))
+    _unit_params_bwd(0, specs[0], fold, p, bufs, x0, ds, sum_s, N, H, W, sink, False)   # exact fp32 in both modes
+    return sink.ret
+
+
+class Decisions(list):
+    """ReLU decisions of a forward pass (a list, in execution order) + the max-pool winners (`pool_taps`, NCHW uint8)."""
+    pool_taps: Optional[torch.Tensor] = None
 
 
 def relu_decisions(state) -> List[torch.Tensor]:
     """The 0/1 decision of every ReLU of a forward pass, in execution order (stem, relu1/relu2/relu_out per
     bottleneck, projector), as NCHW bool tensors on the CPU.  Used by the parity tests: gradients of a ReLU network
-    are only comparable between two fp32 implementations under identical decisions (see oracle/ref_image.ReluPolicy)."""
-    fold, x0, stem, idx, pooled, binfo, cur, pj1, _ = state
-    acts = [stem]
+    are only comparable between two fp32 implementations under identical decisions (see oracle/ref_image.ReluPolicy).
+    Planes mode keeps the decisions as bit masks; the stem's come from its output, which `capture_relu_decisions` makes the
+    forward keep for this purpose."""
+    fold, x0, stem, idx, pooled, binfo, cur, pj1, mp, w3p, dims, pl = state
+    N, H, W, Hs, Ws, h, w = dims
+
+    def nchw(t):
+        return (t > 0).permute(0, 3, 1, 2).contiguous().cpu()
+
+    taps = idx.permute(0, 3, 1, 2).contiguous().cpu()
+    if not pl:
+        acts = [stem]
+        for b in binfo:
+            acts += [b[1], b[2], b[3]]
+        acts.append(pj1)
+        out = Decisions(nchw(a) for a in acts)
+        out.pool_taps = taps
+        return out
+    if stem is None:
+        raise RuntimeError("relu_decisions: the stem output was not kept (run the forward inside capture_relu_decisions())")
+    out = Decisions([nchw(stem.float())])
+    out.pool_taps = taps
     for b in binfo:
-        acts += [b[1], b[2], b[3]]
-    acts.append(pj1)
-    return [(a > 0).permute(0, 3, 1, 2).contiguous().cpu() for a in acts]
+        _, _, _, _, hi, wi, h2, w2, m1, m2, m3 = b
+        for m, hh, ww in ((m1, hi, wi), (m2, h2, w2), (m3, h2, w2)):
+            C = m.shape[1] * 8
+            out.append(K.unpack_mask(m, C).view(N, hh, ww, C).permute(0, 3, 1, 2).contiguous())
+    C = mp.shape[1] * 8
+    out.append(K.unpack_mask(mp, C).view(N, h, w, C).permute(0, 3, 1, 2).contiguous())
+    return out
 
 
 _capture: Optional[list] = None
+_debug: Optional[dict] = None      # diagnostics (scripts/exp_grad_err.py): set to a dict to receive the stem's gradient tensors
 
 
 class capture_relu_decisions:
@@ -289,12 +402,11 @@ class ImageEncodeFn(torch.autograd.Function):
         save = any(t.requires_grad for t in params)
         p = [t.detach() for t in params]
         b = [t.detach() for t in bufs]
-        emb, patch, state = _forward(specs, blocks, p, b, x.detach(), save, want_patch)
+        emb, patch, state = _forward(specs, blocks, p, b, x.detach(), save, want_patch, keep_stem=_capture is not None)
         if save:
-            ctx.state, ctx.p, ctx.b, ctx.meta = state, p, b, meta
+            ctx.state, ctx.p, ctx.b, ctx.meta, ctx.params = state, p, b, meta, params
             if _capture is not None:
                 _capture.append(relu_decisions(state))
-        ctx.mark_non_differentiable(*[])
         if patch is None:
             patch = emb.new_empty(0)
         return emb, patch
@@ -304,6 +416,47 @@ class ImageEncodeFn(torch.autograd.Function):
         specs, blocks, n_params, want_patch = ctx.meta
         if dpatch is not None and dpatch.numel() == 0:
             dpatch = None
-        grads = _backward(specs, blocks, ctx.p, ctx.b, ctx.state, demb, dpatch)
+        sink = GradSink(ctx.params)
+        grads = _backward(specs, blocks, ctx.p, ctx.b, ctx.state, demb, dpatch, sink)
         ctx.state = None
         return (None, None) + tuple(grads) + (None,) * len(ctx.b)
+
+
+@torch.no_grad()
+def forward_stages(specs, blocks, params, bufs, x: torch.Tensor) -> List[torch.Tensor]:
+    """Diagnostic (parity tests): the trunk's stage outputs [max-pooled stem, layer1, layer2, layer3, layer4] as fp32 NCHW
+    tensors, from the same kernels `ImageEncodeFn` runs."""
+    stages: list = []
+    _forward(specs, blocks, [t.detach() for t in params], [t.detach() for t in bufs], x, False, False, stages=stages)
+    out = []
+    for t in stages:
+        f = t.float() if isinstance(t, Planes) else t
+        out.append(K.nhwc_to_nchw(f.contiguous()))
+    return out
+
+
+@torch.no_grad()
+def project_patches(specs, params, bufs, patch_nchw: torch.Tensor) -> torch.Tensor:
+    """The projector alone (`modules.MLP`, reference modules.py:29-47): trunk patch embeddings [N,2048,h,w] -> projected patch
+    embeddings [N,J,h,w], on the same kernels the encoder uses (fixture check against the reference's own MLP)."""
+    N, C, h, w = patch_nchw.shape
+    pl = _planes_mode()
+    ip = len(specs) - 1
+    s = specs[ip]
+    p = [t.detach() for t in params]
+    bufs = [t.detach() for t in bufs]
+    dev = patch_nchw.device
+    fold = _Fold(specs, dev, pl)
+    args = (_filter_rsc(p[3 * ip]), p[3 * ip + 1], p[3 * ip + 2], bufs[2 * ip], bufs[2 * ip + 1], BN_EPS, s.cout, 1, s.cin, s.cpad)
+    (K.bn_fold_pl if pl else K.bn_fold)(*args, fold.ws(ip, s), fold.scale(ip, s), fold.shift(ip, s), fold.rstd(ip, s))
+    x = K.nchw_to_nhwc(patch_nchw.contiguous(), C)
+    if pl:
+        x = K.split_planes(x)
+    pj1, _ = _conv(ip, s, fold, x, None, True, N, h, w, pl, want_mask=False)
+    w3, b3 = p[3 * len(specs)], p[3 * len(specs) + 1]
+    w3m = w3.reshape(w3.shape[0], -1)
+    if pl:
+        pj2 = K.linear_fwd_pl(pj1.view(N * h * w, pj1.shape[-1]), K.split_planes(w3m), b3)
+    else:
+        pj2 = K.linear_fwd(pj1.view(N * h * w, -1), w3m, b3)
+    return K.nhwc_to_nchw(pj2.view(N, h, w, -1))

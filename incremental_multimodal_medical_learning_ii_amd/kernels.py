@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import check
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-AUX_NONE, AUX_RELU_MASK, AUX_GELU_GRAD = 0, 1, 2
+AUX_NONE, AUX_RELU_MASK, AUX_GELU_GRAD, AUX_MASK_BITS = 0, 1, 2, 3
 
 
 def _stream() -> int:
@@ -41,6 +41,83 @@ def _rowmajor2d(t: torch.Tensor, name: str) -> Tuple[torch.Tensor, int]:
     if t.shape[1] != 1 and t.stride(1) != 1:
         t = t.contiguous()
     return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
+
+
+class Planes:
+    """A tensor in split-bf16 storage: `t` is a bf16 tensor [2, *shape] — plane 0 = bf16(x), plane 1 = bf16(x - plane 0) — i.e. the
+    same 4 bytes per element as fp32, x ~ hi + lo to ~2^-17 relative.  It is the activation / weight format of the encoders in
+    split-bf16 mode: the MFMA mainloops load the planes as they are (no conversion work), see csrc/gemm_loaders.h."""
+    __slots__ = ("t",)
+
+    def __init__(self, t: torch.Tensor):
+        if t.dtype != torch.bfloat16 or t.dim() < 2 or t.shape[0] != 2 or not t.is_cuda:
+            raise ValueError(f"Planes: expected a bf16 GPU tensor [2, ...], got {t.dtype} {tuple(t.shape)} on {t.device}")
+        self.t = t
+
+    @staticmethod
+    def empty(*shape, device) -> "Planes":
+        return Planes(torch.empty((2,) + tuple(shape), dtype=torch.bfloat16, device=device))
+
+    @staticmethod
+    def zeros(*shape, device) -> "Planes":
+        return Planes(torch.zeros((2,) + tuple(shape), dtype=torch.bfloat16, device=device))
+
+    @property
+    def shape(self):
+        return self.t.shape[1:]
+
+    @property
+    def device(self):
+        return self.t.device
+
+    @property
+    def plane(self) -> int:
+        """distance between the hi and the lo plane, in elements"""
+        return self.t.stride(0)
+
+    def ptr(self) -> int:
+        return self.t.data_ptr()
+
+    def numel(self) -> int:
+        return self.t.numel() // 2
+
+    def view(self, *shape) -> "Planes":
+        return Planes(self.t.view((2,) + tuple(shape)))
+
+    def rows(self, sl) -> "Planes":
+        """row slice / strided row view of a 2-D planes tensor"""
+        return Planes(self.t[:, sl])
+
+    def is_contiguous(self) -> bool:
+        return self.t[0].is_contiguous()
+
+    def float(self) -> torch.Tensor:
+        """fp32 value hi + lo (host-side consumers, tests)"""
+        if self.is_contiguous() and self.numel() % 8 == 0:
+            out = torch.empty(tuple(self.shape), dtype=torch.float32, device=self.t.device)
+            check(_lib.load().cxrk_merge_planes(self.ptr(), self.plane, self.numel(), _p(out), _stream()), "cxrk_merge_planes")
+            return out
+        return self.t[0].float() + self.t[1].float()
+
+
+def split_planes(x: torch.Tensor, out: Optional[Planes] = None) -> Planes:
+    """fp32 tensor -> its split-bf16 planes (numel % 8 == 0, contiguous)."""
+    _chk(x, "split_planes.x")
+    x = x.contiguous()
+    if out is None:
+        out = Planes.empty(*x.shape, device=x.device)
+    check(_lib.load().cxrk_split_planes(_p(x), x.numel(), out.ptr(), out.plane, _stream()), "cxrk_split_planes")
+    return out
+
+
+def _pl2d(t: Planes, name: str):
+    """(pointer, row stride, plane stride) of a 2-D planes operand with contiguous columns"""
+    if not isinstance(t, Planes) or len(t.shape) != 2:
+        raise ValueError(f"{name}: expected a 2-D Planes tensor")
+    v = t.t
+    if v.shape[2] != 1 and v.stride(2) != 1:
+        raise ValueError(f"{name}: planes columns must be contiguous")
+    return v.data_ptr(), (v.stride(1) if v.shape[1] > 1 else max(v.shape[2], v.stride(1))), v.stride(0)
 
 
 class LaunchProfiler:
@@ -92,10 +169,14 @@ def _kern(flops: float, exact: bool = False) -> str:
     return "gemm_x3_kernel" if split else "gemm_f32_kernel"
 
 
-def _label(la: str, lb: str, tile: str, M: int, N: int, K: int, splitk: int, kind: int, exact: bool = False) -> str:
-    """Profiler key of a launch: mainloop<A loader,B loader,tile>; the 256x256 kernel when the library would pick it."""
-    if not exact and _lib.load().cxrk_gemm_wide_tile(M, N, K, splitk, kind):
-        return f"gemm_x3w_kernel<{la},{lb}>"
+def _label(la: str, lb: str, tile: str, M: int, N: int, K: int, splitk: int, kind: int, exact: bool = False,
+           planes: bool = False) -> str:
+    """Profiler key of a launch: mainloop<A loader,B loader,tile>; planes operands take the 256x256 LDS-DMA kernel when the
+    library's policy picks it, else the split-bf16 mainloop on the 128x128-class tiles."""
+    if planes:
+        if _lib.load().cxrk_gemm_wide_tile(M, N, K, splitk, kind):
+            return f"gemm_pw_kernel<Dma{la},Dma{lb}>"
+        return f"gemm_x3_kernel<{la}<PL>,{lb}<PL>,{tile}>"
     return f"{_kern(2.0 * M * N * K, exact)}<{la},{lb},{tile}>"
 
 
@@ -191,8 +272,8 @@ def linear_bwd_data(dy: torch.Tensor, w: torch.Tensor, aux=None, auxmode: int = 
     return gemm(dy, w, out, M, K, N, False, False, aux=aux, auxmode=auxmode, residual=residual, accumulate=accumulate)
 
 
-def _wgrad_splitk(n_out: int, n_in: int, rows: int) -> int:
-    return int(_lib.load().cxrk_gemm_wgrad_splitk(n_out, n_in, rows))
+def _wgrad_splitk(n_out: int, n_in: int, rows: int, planes: bool = False) -> int:
+    return int(_lib.load().cxrk_gemm_wgrad_splitk(n_out, n_in, rows, int(planes)))
 
 
 def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
@@ -205,7 +286,111 @@ def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accum
     return gemm(dy, x, dw, N, K, M, True, False, accumulate=accumulate)
 
 
+def gemm_pl(a: Planes, b: Planes, M: int, N: int, K: int, trans_a: bool, trans_b: bool, out=None, bias=None, residual=None,
+            aux=None, auxmode: int = 0, maskin=None, maskout=None, preact_out=None, act: int = 0, alpha: float = 1.0,
+            accumulate: bool = False, splitk: int = 1):
+    """The GEMM family on planes operands.  `out`: fp32 tensor or Planes (row-major [M, N]); `residual`: fp32 tensor or Planes;
+    `aux` (auxmode 2): fp32 pre-activation for gelu'; `maskin` (auxmode 3) / `maskout` (with ReLU): uint8 bit masks [M, N/8]."""
+    lib = _lib.load()
+    ap, lda, apl = _pl2d(a, "gemm_pl.a")
+    bp, ldb, bpl = _pl2d(b, "gemm_pl.b")
+    C = Cp = None
+    cpl = 0
+    if isinstance(out, Planes):
+        Cp, ldc, cpl = _pl2d(out, "gemm_pl.out")
+    else:
+        _chk(out, "gemm_pl.out")
+        if out.dim() != 2 or out.stride(1) != 1:
+            raise ValueError("gemm_pl.out must be a row-major 2-D tensor")
+        C, ldc = out.data_ptr(), out.stride(0)
+    R = Rp = None
+    ldr = rpl = 0
+    if isinstance(residual, Planes):
+        Rp, ldr, rpl = _pl2d(residual, "gemm_pl.residual")
+    elif residual is not None:
+        residual, ldr = _rowmajor2d(residual, "gemm_pl.residual")
+        R = residual.data_ptr()
+    ldaux = ldc2 = ldmi = ldmo = 0
+    if aux is not None:
+        aux, ldaux = _rowmajor2d(aux, "gemm_pl.aux")
+    if preact_out is not None:
+        _chk(preact_out, "gemm_pl.preact_out")
+        ldc2 = preact_out.stride(0)
+    if maskin is not None:
+        _chk(maskin, "gemm_pl.maskin", torch.uint8)
+        ldmi = maskin.stride(0)
+    if maskout is not None:
+        _chk(maskout, "gemm_pl.maskout", torch.uint8)
+        ldmo = maskout.stride(0)
+    if bias is not None:
+        _chk(bias, "gemm_pl.bias")
+        if bias.numel() != N or not bias.is_contiguous():
+            raise ValueError("gemm_pl.bias must be contiguous with N elements")
+    ws, wsb = None, 0
+    if splitk > 1:
+        wsb = lib.cxrk_gemm_splitk_ws_bytes(M, N, splitk)
+        ws = workspace(wsb, a.device)
+        wsb = ws.numel() * 4
+    plain = bias is None and residual is None and aux is None and maskin is None and preact_out is None and act == 0
+    ev = profiler.bracket(_label(f"Dense{'MC' if trans_a else 'KC'}", f"Dense{'KC' if trans_b else 'MC'}", _tile(M, N), M, N, K, splitk,
+                                 0 if (plain or splitk > 1) else 3, planes=True), 2.0 * M * N * K,
+                          4.0 * (M * K + N * K + M * N * (1 + (residual is not None) + (aux is not None) + (preact_out is not None)
+                                                       + int(bool(accumulate)))) + M * N / 8.0 * ((maskin is not None) + (maskout is not None))) if profiler.on else None
+    rc = lib.cxrk_gemm_pl(int(trans_a), int(trans_b), M, N, K, ap, lda, apl, bp, ldb, bpl, C, Cp, ldc, cpl, _p(bias), R, Rp, ldr, rpl,
+                          _p(aux), ldaux, auxmode, _p(maskin), ldmi, _p(maskout), ldmo, _p(preact_out), ldc2, act, float(alpha),
+                          int(accumulate), int(splitk), _p(ws), wsb, _stream())
+    if ev is not None:
+        ev.record()
+    check(rc, f"cxrk_gemm_pl(M={M},N={N},K={K},tA={trans_a},tB={trans_b})")
+    return out
+
+
+def linear_fwd_pl(x: Planes, w: Planes, bias=None, act: int = 0, residual=None, preact_out=None, out=None, out_planes: bool = False,
+                  maskout=None):
+    """y[M,N] = act(x[M,K] @ w[N,K]^T + bias + residual); y as fp32 (default) or Planes."""
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"linear_fwd_pl: x is [{M},{K}] but w is {tuple(w.shape)}")
+    if out is None:
+        out = Planes.empty(M, N, device=x.device) if out_planes else torch.empty(M, N, dtype=torch.float32, device=x.device)
+    return gemm_pl(x, w, M, N, K, False, True, out=out, bias=bias, residual=residual, preact_out=preact_out, act=act, maskout=maskout)
+
+
+def linear_bwd_data_pl(dy: Planes, w: Planes, aux=None, auxmode: int = 0, maskin=None, residual=None, out=None,
+                       out_planes: bool = False, accumulate: bool = False):
+    """dx[M,K] = (dy[M,N] @ w[N,K] + residual) (* gelu'(aux) | * mask bits)."""
+    M, N = dy.shape
+    K = w.shape[1]
+    if out is None:
+        out = Planes.empty(M, K, device=dy.device) if out_planes else torch.empty(M, K, dtype=torch.float32, device=dy.device)
+    if maskin is not None:
+        auxmode = AUX_MASK_BITS
+    return gemm_pl(dy, w, M, K, N, False, False, out=out, aux=aux, auxmode=auxmode, maskin=maskin, residual=residual, accumulate=accumulate)
+
+
+def linear_bwd_weight_pl(dy: Planes, x: Planes, dw: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    """dw[N,K] (+)= dy[M,N]^T @ x[M,K]  (deterministic split-K over M); dw fp32."""
+    M, N = dy.shape
+    K = x.shape[1]
+    sk = _wgrad_splitk(N, K, M, planes=True)
+    return gemm_pl(dy, x, N, K, M, True, False, out=dw, accumulate=accumulate, splitk=sk if sk > 1 else 1)
+
+
+def colsum_pl(x: Planes, out: torch.Tensor, alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:
+    lib = _lib.load()
+    xp, ldx, xpl = _pl2d(x, "colsum_pl.x")
+    _chk(out, "colsum_pl.out")
+    rows, cols = x.shape
+    ws = workspace(lib.cxrk_colsum_ws_bytes(rows, cols), x.device)
+    check(lib.cxrk_colsum_pl(xp, ldx, xpl, rows, cols, _p(out), float(alpha), int(accumulate), _p(ws), ws.numel() * 4, _stream()),
+          "cxrk_colsum_pl")
+    return out
+
+
 def colsum(x: torch.Tensor, out: torch.Tensor, alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:
+    if isinstance(x, Planes):
+        return colsum_pl(x, out, alpha, accumulate)
     lib = _lib.load()
     x, ldx = _rowmajor2d(x, "colsum.x")
     _chk(out, "colsum.out")
@@ -246,72 +431,163 @@ def conv_fwd(x, w_scaled, shift, residual, y, N, H, W, C, Ko, R, S, stride, pad,
     return y
 
 
-def conv_bwd_data(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R, S, stride, pad):
+def _conv_out(H, W, R, S, stride, pad):
+    return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+
+
+def conv_bwd_data(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R, S, stride, pad, sums=None):
+    """dx = (relu_src > 0) * (conv^T(dy, w_scaled) + residual); `sums` ([C], optional) receives the column sums of dx (the BN beta
+    gradient of the unit that produced relu_src), reduced in the same epilogue."""
     lib = _lib.load()
+    ws = workspace(lib.cxrk_conv_bwd_data_colsum_ws_bytes(N, H, W, C, stride), dy.device) if sums is not None else None
     ev = None
     if profiler.on:  # algorithmic FLOPs of a data gradient = those of the forward conv (stride-2 zero taps are waste)
-        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        Ho, Wo = _conv_out(H, W, R, S, stride, pad)
         fl = 2.0 * N * Ho * Wo * Ko * R * S * C
         ev = profiler.bracket(_label("ConvDgradKC", "ConvFilterMC", "4,1" if C <= 64 else "2,2", N * H * W, C, R * S * Ko, 1,
                                      2 if stride == 1 else 3), fl,
                               4.0 * (N * Ho * Wo * Ko + Ko * R * S * C + N * H * W * C * (1 + (residual is not None) + (relu_src is not None))))
     rc = lib.cxrk_conv_bn_act_bwd_data(_p(_chk(dy, "conv.dy")), _p(w_scaled), _p(residual), _p(relu_src), _p(dx), N, H,
-                                       W, C, Ko, R, S, stride, pad, _stream())
+                                       W, C, Ko, R, S, stride, pad, _p(sums), _p(ws), ws.numel() * 4 if ws is not None else 0, _stream())
     if ev is not None:
         ev.record()
     check(rc, f"cxrk_conv_bn_act_bwd_data(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
     return dx
 
 
-def bn_bwd_reduce(dy, y, sub, beta, sumdy, sumdyy):
-    """sumdy[c] = sum dy; sumdyy[c] = sum dy*(y - sub - beta[c]) over all rows of the [rows, C] views."""
-    lib = _lib.load()
-    C = dy.shape[-1]
-    rows = dy.numel() // C
-    ws = workspace(lib.cxrk_bn_bwd_reduce_ws_bytes(rows, C), dy.device)
-    check(lib.cxrk_bn_bwd_reduce(_p(_chk(dy, "bn_reduce.dy")), _p(_chk(y, "bn_reduce.y")), _p(sub), _p(beta), rows, C,
-                                 _p(sumdy), _p(sumdyy), _p(ws), ws.numel() * 4, _stream()), "cxrk_bn_bwd_reduce")
-
-
-def conv_bwd_data_bnsum(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R, S, stride, pad, bn_sub, bn_beta, bn_beta2, sums):
-    """conv_bwd_data + the BN-backward channel sums of the unit that produced `relu_src` (sums [3,C])."""
-    lib = _lib.load()
-    ws = workspace(lib.cxrk_conv_bwd_data_bnsum_ws_bytes(N, H, W, C, stride), dy.device)
-    ev = None
-    if profiler.on:
-        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
-        fl = 2.0 * N * Ho * Wo * Ko * R * S * C
-        ev = profiler.bracket(_label("ConvDgradKC", "ConvFilterMC", "4,1" if C <= 64 else "2,2", N * H * W, C, R * S * Ko, 1,
-                                     2 if stride == 1 else 3), fl,
-                              4.0 * (N * Ho * Wo * Ko + Ko * R * S * C + N * H * W * C * (2 + (residual is not None) + (bn_sub is not None))))
-    rc = lib.cxrk_conv_bn_act_bwd_data_bnsum(_p(_chk(dy, "conv.dy")), _p(w_scaled), _p(residual), _p(relu_src), _p(dx), N, H, W, C,
-                                             Ko, R, S, stride, pad, _p(bn_sub), _p(bn_beta), _p(bn_beta2), _p(sums), _p(ws),
-                                             ws.numel() * 4, _stream())
-    if ev is not None:
-        ev.record()
-    check(rc, f"cxrk_conv_bn_act_bwd_data_bnsum(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
-    return dx
-
-
-def conv_bwd_params(x, dy, w, scale, rstd, rmean, sumdy, gamma, sumdyy, dw, dgamma, dbeta, accumulate, N, H, W, C, Cpad,
-                    Ko, R, S, stride, pad):
+def conv_bwd_params(x, dy, w, scale, rstd, rmean, sumdy, dw, dgamma, dbeta, accumulate, N, H, W, C, Cpad, Ko, R, S, stride, pad):
+    """dW = scale * wgrad(x, dy); dbeta = sumdy; dgamma = rstd * (<w, wgrad> - mean * sumdy)  (csrc/conv.hip)."""
     lib = _lib.load()
     wsb = lib.cxrk_conv_wgrad_ws_bytes(N, H, W, Cpad, Ko, R, S, stride, pad)
     ws = workspace(wsb, x.device)
     ev = None
     if profiler.on:
-        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        Ho, Wo = _conv_out(H, W, R, S, stride, pad)
         fl = 2.0 * N * Ho * Wo * Ko * R * S * Cpad
-        sk = lib.cxrk_gemm_wgrad_splitk(Ko, R * S * Cpad, N * Ho * Wo)
+        sk = lib.cxrk_gemm_wgrad_splitk(Ko, R * S * Cpad, N * Ho * Wo, 0)
         ev = profiler.bracket(_label("DenseMC", "ConvIm2colMC", "1,4" if Ko <= 64 else "2,2", Ko, R * S * Cpad, N * Ho * Wo, sk, 0,
                                      Cpad <= 4), fl, 4.0 * (N * H * W * Cpad + N * Ho * Wo * Ko + Ko * R * S * Cpad))
     check(lib.cxrk_conv_bn_act_bwd_params(_p(_chk(x, "conv.x")), _p(_chk(dy, "conv.dy")), _p(w), _p(scale), _p(rstd),
-                                          _p(rmean), _p(sumdy), _p(gamma), _p(sumdyy), _p(dw), _p(dgamma), _p(dbeta),
-                                          int(accumulate), N, H, W,
+                                          _p(rmean), _p(sumdy), _p(dw), _p(dgamma), _p(dbeta), int(accumulate), N, H, W,
                                           C, Cpad, Ko, R, S, stride, pad, _p(ws), ws.numel() * 4, _stream()),
           f"cxrk_conv_bn_act_bwd_params(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
     if ev is not None:
         ev.record()
+
+
+# ---- planes storage (split-bf16 mode of the image encoder) -------------------------------------------------------------------
+
+def bn_fold_pl(w, gamma, beta, rmean, rvar, eps, Ko, taps, C, Cpad, w_scaled: Planes, scale, shift, rstd):
+    lib = _lib.load()
+    for n, t in (("w", w), ("gamma", gamma), ("beta", beta), ("rmean", rmean), ("rvar", rvar)):
+        _chk(t, "bn_fold." + n)
+    check(lib.cxrk_bn_fold_pl(_p(w), _p(gamma), _p(beta), _p(rmean), _p(rvar), float(eps), Ko, taps, C, Cpad, w_scaled.ptr(),
+                              w_scaled.plane, _p(scale), _p(shift), _p(rstd), _stream()), "cxrk_bn_fold_pl")
+
+
+def conv_fwd_pl(x, w_scaled, shift, residual: Optional[Planes], y: Planes, maskout, N, H, W, C, Ko, R, S, stride, pad, relu):
+    """x / w_scaled: both Planes, or both fp32 tensors (the stem); y (and residual) Planes; maskout: uint8 [N*Ho*Wo, Ko/8] or None."""
+    lib = _lib.load()
+    in_planes = isinstance(x, Planes)
+    if in_planes != isinstance(w_scaled, Planes):
+        raise ValueError("conv_fwd_pl: x and w_scaled must share the storage format")
+    ev = None
+    if profiler.on:
+        Ho, Wo = _conv_out(H, W, R, S, stride, pad)
+        fl = 2.0 * N * Ho * Wo * Ko * R * S * C
+        nb = 4.0 * (N * H * W * C + Ko * R * S * C + N * Ho * Wo * Ko * (1 + (residual is not None))) + (N * Ho * Wo * Ko / 8.0 if maskout is not None else 0.0)
+        if in_planes:
+            key = _label("ConvIm2colKC", "DenseKC", "4,1" if Ko <= 64 else "2,2", N * Ho * Wo, Ko, R * S * C, 1, 1, planes=True)
+        else:
+            key = _label("ConvIm2colKC", "DenseKC", "4,1" if Ko <= 64 else "2,2", N * Ho * Wo, Ko, R * S * C, 1, 3)
+        ev = profiler.bracket(key, fl, nb)
+    if maskout is not None:
+        _chk(maskout, "conv.maskout", torch.uint8)
+    xp, xpl = (x.ptr(), x.plane) if in_planes else (_p(_chk(x, "conv.x")), 0)
+    wp, wpl = (w_scaled.ptr(), w_scaled.plane) if in_planes else (_p(_chk(w_scaled, "conv.w")), 0)
+    rc = lib.cxrk_conv_bn_act_fwd_pl(xp, xpl, wp, wpl, int(in_planes), _p(shift), residual.ptr() if residual is not None else None,
+                                     residual.plane if residual is not None else 0, y.ptr(), y.plane, _p(maskout), N, H, W, C, Ko, R, S,
+                                     stride, pad, int(relu), _stream())
+    if ev is not None:
+        ev.record()
+    check(rc, f"cxrk_conv_bn_act_fwd_pl(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
+    return y
+
+
+def conv_bwd_data_pl(dy: Planes, w_scaled: Planes, residual: Optional[Planes], maskin, dx: Planes, N, H, W, C, Ko, R, S, stride, pad,
+                     sums=None):
+    lib = _lib.load()
+    ws = workspace(lib.cxrk_conv_bwd_data_colsum_ws_bytes(N, H, W, C, stride), dy.device) if sums is not None else None
+    ev = None
+    if profiler.on:
+        Ho, Wo = _conv_out(H, W, R, S, stride, pad)
+        fl = 2.0 * N * Ho * Wo * Ko * R * S * C
+        ev = profiler.bracket(_label("ConvDgradKC", "ConvFilterMC", "4,1" if C <= 64 else "2,2", N * H * W, C, R * S * Ko, 1,
+                                     2 if stride == 1 else 3, planes=True), fl,
+                              4.0 * (N * Ho * Wo * Ko + Ko * R * S * C + N * H * W * C * (1 + (residual is not None)))
+                              + (N * H * W * C / 8.0 if maskin is not None else 0.0))
+    rc = lib.cxrk_conv_bn_act_bwd_data_pl(dy.ptr(), dy.plane, w_scaled.ptr(), w_scaled.plane, residual.ptr() if residual is not None else None,
+                                          residual.plane if residual is not None else 0, _p(maskin), dx.ptr(), dx.plane, N, H, W, C, Ko, R, S,
+                                          stride, pad, _p(sums), _p(ws), ws.numel() * 4 if ws is not None else 0, _stream())
+    if ev is not None:
+        ev.record()
+    check(rc, f"cxrk_conv_bn_act_bwd_data_pl(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
+    return dx
+
+
+def conv_bwd_params_pl(x: Planes, dy: Planes, w, scale, rstd, rmean, sumdy, dw, dgamma, dbeta, accumulate, N, H, W, C, Ko, R, S, stride, pad):
+    lib = _lib.load()
+    ws = workspace(lib.cxrk_conv_wgrad_ws_bytes(N, H, W, C, Ko, R, S, stride, pad), x.device)
+    ev = None
+    if profiler.on:
+        Ho, Wo = _conv_out(H, W, R, S, stride, pad)
+        fl = 2.0 * N * Ho * Wo * Ko * R * S * C
+        sk = lib.cxrk_gemm_wgrad_splitk(Ko, R * S * C, N * Ho * Wo, 1)
+        ev = profiler.bracket(_label("DenseMC", "ConvIm2colMC", "1,4" if Ko <= 64 else "2,2", Ko, R * S * C, N * Ho * Wo, sk, 0, planes=True),
+                              fl, 4.0 * (N * H * W * C + N * Ho * Wo * Ko + Ko * R * S * C))
+    check(lib.cxrk_conv_bn_act_bwd_params_pl(x.ptr(), x.plane, dy.ptr(), dy.plane, _p(w), _p(scale), _p(rstd), _p(rmean), _p(sumdy),
+                                             _p(dw), _p(dgamma), _p(dbeta), int(accumulate), N, H, W, C, Ko, R, S, stride, pad, _p(ws),
+                                             ws.numel() * 4, _stream()),
+          f"cxrk_conv_bn_act_bwd_params_pl(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
+    if ev is not None:
+        ev.record()
+
+
+def maxpool_fwd_pl(x: Planes):
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = Planes.empty(N, Ho, Wo, C, device=x.device)
+    idx = torch.empty(N, Ho, Wo, C, dtype=torch.uint8, device=x.device)
+    check(lib.cxrk_maxpool_fwd_pl(x.ptr(), x.plane, y.ptr(), y.plane, _p(idx), N, H, W, C, _stream()), "cxrk_maxpool_fwd_pl")
+    return y, idx
+
+
+def maxpool_bwd_pl(dy: Planes, idx, pooled: Planes, H: int, W: int) -> torch.Tensor:
+    """fp32 gradient w.r.t. the (post-ReLU) stem output, masked by the stem ReLU through the sign of `pooled`."""
+    lib = _lib.load()
+    N, _, _, C = pooled.shape
+    dx = torch.empty(N, H, W, C, dtype=torch.float32, device=dy.device)
+    check(lib.cxrk_maxpool_bwd_pl(dy.ptr(), dy.plane, _p(idx), pooled.ptr(), _p(dx), N, H, W, C, _stream()), "cxrk_maxpool_bwd_pl")
+    return dx
+
+
+def spatial_mean_bwd_pl(dy: torch.Tensor, Pn: int, add: Optional[torch.Tensor] = None) -> Planes:
+    lib = _lib.load()
+    N, C = dy.shape
+    dx = Planes.empty(N, Pn, C, device=dy.device)
+    if add is not None:
+        add = _chk(add, "spatial_mean.add").contiguous()
+    check(lib.cxrk_spatial_mean_bwd_pl(_p(_chk(dy.contiguous(), "spatial_mean.dy")), _p(add), dx.ptr(), dx.plane, N, Pn, C, _stream()),
+          "cxrk_spatial_mean_bwd_pl")
+    return dx
+
+
+def unpack_mask(mask: torch.Tensor, C: int) -> torch.Tensor:
+    """ReLU decision bits [rows, C/8] (bit c % 8 of byte c / 8) -> bool [rows, C] on the host (tests only)."""
+    m = mask.cpu().reshape(-1, C // 8).to(torch.int32)
+    bits = (m.unsqueeze(-1) >> torch.arange(8, dtype=torch.int32)) & 1
+    return bits.reshape(-1, C).bool()
 
 
 def nchw_to_nhwc(x: torch.Tensor, cpad: int) -> torch.Tensor:
@@ -373,60 +649,85 @@ def spatial_mean_bwd(dy: torch.Tensor, Pn: int) -> torch.Tensor:
 # text encoder pieces
 # ----------------------------------------------------------------------------------------------------------------
 
-def embed_ln_fwd(ids, word, pos, type_row, gamma, beta, eps, L):
+def _new_out(rows, cols, device, planes: bool):
+    """(tensor-or-Planes, pointer, plane stride) of a fresh [rows, cols] output in the requested storage format"""
+    if planes:
+        o = Planes.empty(rows, cols, device=device)
+        return o, o.ptr(), o.plane
+    o = torch.empty(rows, cols, dtype=torch.float32, device=device)
+    return o, o.data_ptr(), 0
+
+
+def embed_ln_fwd(ids, word, pos, type_row, gamma, beta, eps, L, out_planes: bool = False):
     lib = _lib.load()
     _chk(ids, "embed.ids", torch.int64)
     ids = ids.contiguous()
     T = ids.numel()
     H = word.shape[1]
-    y = torch.empty(T, H, dtype=torch.float32, device=word.device)
-    xhat = torch.empty_like(y)
+    y, yp, ypl = _new_out(T, H, word.device, out_planes)
+    xhat = torch.empty(T, H, dtype=torch.float32, device=word.device)
     rstd = torch.empty(T, dtype=torch.float32, device=word.device)
     check(lib.cxrk_embed_ln_fwd(_p(ids), _p(_chk(word, "embed.word")), _p(pos), _p(type_row), _p(gamma), _p(beta),
-                                float(eps), T, L, H, _p(y), _p(xhat), _p(rstd), _stream()), "cxrk_embed_ln_fwd")
+                                float(eps), T, L, H, yp, ypl, _p(xhat), _p(rstd), _stream()), "cxrk_embed_ln_fwd")
     return y, xhat, rstd
 
 
-def residual_ln_fwd(x, res, gamma, beta, eps, save: bool = True):
+def residual_ln_fwd(x, res, gamma, beta, eps, save: bool = True, out_planes: bool = False):
     lib = _lib.load()
     rows, H = x.shape
-    y = torch.empty_like(x)
+    y, yp, ypl = _new_out(rows, H, x.device, out_planes)
     xhat = torch.empty_like(x) if save else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
-    check(lib.cxrk_residual_ln_fwd(_p(_chk(x, "ln.x")), _p(res), _p(gamma), _p(beta), float(eps), rows, H, _p(y),
+    check(lib.cxrk_residual_ln_fwd(_p(_chk(x, "ln.x")), _p(res), _p(gamma), _p(beta), float(eps), rows, H, yp, ypl,
                                    _p(xhat), _p(rstd), _stream()), "cxrk_residual_ln_fwd")
     return y, xhat, rstd
 
 
-def residual_ln_bwd(dy, xhat, rstd, gamma, dgamma, dbeta, dx_add=None, accumulate: bool = False, out=None):
+def residual_ln_bwd(dy, xhat, rstd, gamma, dgamma, dbeta, dx_add=None, accumulate: bool = False, out=None, out_planes: bool = False):
     lib = _lib.load()
     rows, H = dy.shape
-    dx = torch.empty_like(dy) if out is None else out
+    if out is None:
+        dx, dxp, dxpl = _new_out(rows, H, dy.device, out_planes)
+    elif isinstance(out, Planes):
+        dx, dxp, dxpl = out, out.ptr(), out.plane
+    else:
+        dx, dxp, dxpl = out, out.data_ptr(), 0
     wsb = lib.cxrk_residual_ln_bwd_ws_bytes(rows, H)
     ws = workspace(wsb, dy.device)
-    check(lib.cxrk_residual_ln_bwd(_p(_chk(dy, "ln.dy")), _p(xhat), _p(rstd), _p(gamma), rows, H, _p(dx_add), _p(dx),
+    check(lib.cxrk_residual_ln_bwd(_p(_chk(dy, "ln.dy")), _p(xhat), _p(rstd), _p(gamma), rows, H, _p(dx_add), dxp, dxpl,
                                    _p(dgamma), _p(dbeta), int(accumulate), _p(ws), ws.numel() * 4, _stream()),
           "cxrk_residual_ln_bwd")
     return dx
 
 
-def attn_fwd(qkv, mask, B, L, nH, dH, save_probs: bool = True):
+def attn_fwd(qkv, mask, B, L, nH, dH, save_probs: bool = True, out_planes: bool = False):
     lib = _lib.load()
-    ctx = torch.empty(B * L, nH * dH, dtype=torch.float32, device=qkv.device)
+    ctx, cp, cpl = _new_out(B * L, nH * dH, qkv.device, out_planes)
     probs = torch.empty(B, nH, L, L, dtype=torch.float32, device=qkv.device) if save_probs else None
     if mask is not None:
         _chk(mask, "attn.mask", torch.int64)
-    check(lib.cxrk_attn_fwd(_p(_chk(qkv, "attn.qkv")), _p(mask), B, L, nH, dH, _p(ctx), _p(probs), _stream()),
+    check(lib.cxrk_attn_fwd(_p(_chk(qkv, "attn.qkv")), _p(mask), B, L, nH, dH, cp, cpl, _p(probs), _stream()),
           f"cxrk_attn_fwd(B={B},L={L},nH={nH},dH={dH})")
     return ctx, probs
 
 
-def attn_bwd(qkv, probs, dctx, B, L, nH, dH):
+def attn_bwd(qkv, probs, dctx, B, L, nH, dH, out_planes: bool = False):
     lib = _lib.load()
-    dqkv = torch.empty_like(qkv)
-    check(lib.cxrk_attn_bwd(_p(qkv), _p(probs), _p(_chk(dctx, "attn.dctx")), B, L, nH, dH, _p(dqkv), _stream()),
+    dqkv, dp, dpl = _new_out(qkv.shape[0], qkv.shape[1], qkv.device, out_planes)
+    check(lib.cxrk_attn_bwd(_p(qkv), _p(probs), _p(_chk(dctx, "attn.dctx")), B, L, nH, dH, dp, dpl, _stream()),
           "cxrk_attn_bwd")
     return dqkv
+
+
+def planes_add_rows(src: Planes, dst: torch.Tensor) -> torch.Tensor:
+    """dst[r, :] += src[r, :] for a row-strided fp32 `dst` view (e.g. the CLS rows of a [N, L*H] gradient)."""
+    lib = _lib.load()
+    rows, cols = src.shape
+    if tuple(dst.shape) != (rows, cols) or dst.stride(1) != 1 or not src.is_contiguous():
+        raise ValueError("planes_add_rows: shape / layout mismatch")
+    check(lib.cxrk_planes_add_rows(src.ptr(), src.plane, rows, cols, _p(_chk(dst, "add_rows.dst")), dst.stride(0), _stream()),
+          "cxrk_planes_add_rows")
+    return dst
 
 
 def embed_bwd(ids, dx, dword):

@@ -39,6 +39,13 @@ class ReluPolicy:
 
     def __init__(self, masks=None):
         self.masks, self.i, self.flips, self.count, self.max_flip_rel = masks, 0, 0, 0, 0.0
+        # The stem max-pool is the same kind of discontinuity: where the two largest values of a 3x3 window are within rounding
+        # of each other, two correct implementations route the window's gradient to different pixels, and because a weight gradient
+        # is a sum of ~sqrt(n)-cancelling terms ONE such re-routing moves the stem's weight gradient by ~1/sqrt(n) (0.6 % at batch
+        # 2).  `masks.pool_taps` (winning tap 3*r + s per pooled output, NCHW) imposes the implementation's winners;
+        # `pool_flips` / `pool_max_gap` report how many differ from the oracle's own and by how much the values differ there.
+        self.pool_taps = getattr(masks, "pool_taps", None)
+        self.pool_flips, self.pool_max_gap = 0, 0.0
 
     def __call__(self, z: torch.Tensor) -> torch.Tensor:
         if self.masks is None:
@@ -51,6 +58,25 @@ class ReluPolicy:
             self.flips += int(diff.sum())
             self.max_flip_rel = max(self.max_flip_rel, float(z[diff].abs().max() / z.abs().max()))
         return z * m.to(z.dtype)
+
+
+    def maxpool(self, x: torch.Tensor) -> torch.Tensor:
+        """nn.MaxPool2d(3, stride 2, padding 1) of the stem (resnet.py:37), optionally with imposed winners."""
+        if self.pool_taps is None:
+            return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        N, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        neg = torch.finfo(x.dtype).min
+        win = F.unfold(F.pad(x, (1, 1, 1, 1), value=neg), kernel_size=3, stride=2).view(N, C, 9, Ho, Wo)
+        taps = self.pool_taps.to(torch.int64).unsqueeze(2)
+        out = win.gather(2, taps).squeeze(2)
+        with torch.no_grad():
+            best, arg = win.max(dim=2)
+            diff = arg != taps.squeeze(2)
+            self.pool_flips = int(diff.sum())
+            if diff.any():
+                self.pool_max_gap = float(((best - out)[diff]).abs().max() / x.abs().max())
+        return out
 
 
 _PLAIN = ReluPolicy()
@@ -74,7 +100,7 @@ def bottleneck(p: P, pre: str, x: torch.Tensor, stride: int, has_down: bool, rel
 def resnet50_trunk(p: P, x: torch.Tensor, prefix: str = "encoder.encoder.", collect: List = None, relu=_PLAIN) -> torch.Tensor:
     x = F.conv2d(x, p[prefix + "conv1.weight"], stride=2, padding=3)
     x = relu(_bn(p, prefix + "bn1", x))
-    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    x = relu.maxpool(x) if hasattr(relu, "maxpool") else F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
     if collect is not None:
         collect.append(x)
     for li, (nblk, planes) in enumerate(zip(LAYERS, PLANES), start=1):

@@ -43,6 +43,19 @@ def precision(request):
         _lib.set_precision(old)
 
 
+@pytest.fixture(params=["policy", "wide"])
+def wide(request):
+    """Planes GEMM / convolution tests run twice: with the library's own tile policy, and with the 256x256 LDS-DMA kernel forced
+    on every planes launch (so small and ragged shapes exercise it too)."""
+    from incremental_multimodal_medical_learning_ii_amd import _lib
+    lib = _lib.load()
+    old = lib.cxrk_set_wide_mode(2 if request.param == "wide" else 1)
+    try:
+        yield request.param
+    finally:
+        lib.cxrk_set_wide_mode(old)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

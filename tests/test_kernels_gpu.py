@@ -139,17 +139,18 @@ def test_conv_bn_relu_fwd_bwd(cfg):
     close(K.nhwc_to_nchw(yd), y, what="conv fwd")
     # backward: mask by own relu (host-side here; fused into the producing dgrad in the model)
     gyd = gy.permute(0, 2, 3, 1).contiguous().to(DEV) * (yd > 0)
-    sums = torch.empty(2, Ko, device=DEV)
-    K.bn_bwd_reduce(gyd, yd, resd, b_, sums[0], sums[1])
+    sumdy = K.colsum(gyd.view(-1, Ko), torch.empty(Ko, device=DEV))
     dw = torch.empty(Ko, R, R, cr, device=DEV)
     dg, db = torch.empty(Ko, device=DEV), torch.empty(Ko, device=DEV)
-    K.conv_bwd_params(xd, gyd, w_cl, sc, rstd, rm_, sums[0], g_, sums[1], dw, dg, db, False, N, H, W, cr, C, Ko, R, R, stride, pad)
+    K.conv_bwd_params(xd, gyd, w_cl, sc, rstd, rm_, sumdy, dw, dg, db, False, N, H, W, cr, C, Ko, R, R, stride, pad)
     close(dw.permute(0, 3, 1, 2), w.grad, tol=5e-5, what="conv wgrad")
-    close(dg, gamma.grad, tol=5e-5, what="bn dgamma")
+    # dgamma = rstd * (<w, dW_raw> - mean * sum dy): exact algebra; on these zero-mean random gradients the sum cancels more than
+    # on a real network (where it was measured at < 1e-6 against the direct form, scripts/exp_dgamma.py)
+    close(dg, gamma.grad, tol=2e-2 if _split() else 2e-3, what="bn dgamma")
     close(db, beta.grad, tol=5e-5, what="bn dbeta")
-    dg2 = torch.empty(Ko, device=DEV)  # fallback formula (no y_bn available): exact algebra, looser conditioning
-    K.conv_bwd_params(xd, gyd, w_cl, sc, rstd, rm_, sums[0], None, None, dw, dg2, db, False, N, H, W, cr, C, Ko, R, R, stride, pad)
-    close(dg2, gamma.grad, tol=2e-2 if _split() else 2e-3, what="bn dgamma (fallback)")  # cancellation amplifies product error
+    K.conv_bwd_params(xd, gyd, w_cl, sc, rstd, rm_, sumdy, dw, dg, db, True, N, H, W, cr, C, Ko, R, R, stride, pad)
+    close(dw.permute(0, 3, 1, 2), 2 * w.grad, tol=5e-5, what="conv wgrad accumulate")
+    close(db, 2 * beta.grad, tol=5e-5, what="bn dbeta accumulate")
     if C != 4:
         dxd = torch.empty(N, H, W, C, device=DEV)
         K.conv_bwd_data(gyd, ws, None, None, dxd, N, H, W, C, Ko, R, R, stride, pad)
@@ -161,15 +162,200 @@ def test_conv_bn_relu_fwd_bwd(cfg):
         else:
             K.conv_bwd_data(gyd, ws, add, xd, dxd, N, H, W, C, Ko, R, R, stride, pad)
             close(K.nhwc_to_nchw(dxd), (x.grad + K.nhwc_to_nchw(add).cpu()) * (x.detach() > 0), tol=5e-5, what="dgrad+res+mask")
-            # same launch with the fused BatchNorm-backward channel sums
-            sub, b1, b2 = rnd(N, H, W, C, seed=12).to(DEV), rnd(C, seed=13).to(DEV), rnd(C, seed=14).to(DEV)
-            sums, dx2 = torch.empty(3, C, device=DEV), torch.empty_like(dxd)
-            K.conv_bwd_data_bnsum(gyd, ws, add, xd, dx2, N, H, W, C, Ko, R, R, stride, pad, sub, b1, b2, sums)
+            # same launch with the fused column sums (the BatchNorm beta gradient of the producing unit)
+            sums, dx2 = torch.empty(C, device=DEV), torch.empty_like(dxd)
+            K.conv_bwd_data(gyd, ws, add, xd, dx2, N, H, W, C, Ko, R, R, stride, pad, sums=sums)
             assert torch.equal(dx2, dxd)
-            v = dxd.double().view(-1, C)
-            close(sums[0], v.sum(0).float(), tol=5e-5, what="bnsum S0")
-            close(sums[1], (v * (xd.double().view(-1, C) - sub.double().view(-1, C) - b1.double())).sum(0).float(), tol=5e-5, what="bnsum S1")
-            close(sums[2], (v * (sub.double().view(-1, C) - b2.double())).sum(0).float(), tol=5e-5, what="bnsum S2")
+            close(sums, dxd.double().view(-1, C).sum(0).float(), tol=5e-5, what="dgrad column sums")
+
+
+@pytest.mark.parametrize("gval", [0.0, 1e-30, 1e-6, 1e-3])
+def test_bn_gamma_gradient_does_not_divide_by_gamma(gval):
+    """dgamma used to be sum(dy*(y_bn - beta)) / gamma — inf / NaN / 1e-2 errors for zero-init-residual or pruned
+    channels.  It is now taken from the weight gradient and must match PyTorch for any gamma."""
+    N, H, C, Ko, R = 2, 10, 64, 64, 3
+    x, w, gamma, beta, rm, rv = _conv_case(N, H, H, C, Ko, R, 1, 1)
+    gamma = torch.full_like(gamma, gval)
+    gamma[::2] = 1.0 + 0.1 * torch.arange(Ko // 2)
+    for t in (x, w, gamma, beta):
+        t.requires_grad_(True)
+    y = F.batch_norm(F.conv2d(x, w, padding=1), rm, rv, gamma, beta, training=False, eps=1e-5)
+    gy = rnd(*y.shape, seed=10)
+    y.backward(gy)
+    xd = K.nchw_to_nhwc(x.detach().to(DEV), C)
+    w_cl = w.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    ws = torch.empty(Ko, R, R, C, device=DEV)
+    sc, sh, rstd = (torch.empty(Ko, device=DEV) for _ in range(3))
+    K.bn_fold(w_cl, gamma.detach().to(DEV), beta.detach().to(DEV), rm.to(DEV), rv.to(DEV), 1e-5, Ko, R * R, C, C, ws, sc, sh, rstd)
+    gyd = gy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    sumdy = K.colsum(gyd.view(-1, Ko), torch.empty(Ko, device=DEV))
+    dw, dg, db = torch.empty(Ko, R, R, C, device=DEV), torch.empty(Ko, device=DEV), torch.empty(Ko, device=DEV)
+    K.conv_bwd_params(xd, gyd, w_cl, sc, rstd, rm.to(DEV), sumdy, dw, dg, db, False, N, H, H, C, C, Ko, R, R, 1, 1)
+    assert torch.isfinite(dg).all()
+    close(dg, gamma.grad, tol=2e-3, what=f"dgamma at gamma={gval}")
+    close(dw.permute(0, 3, 1, 2), w.grad, tol=5e-5, what="dw")
+
+
+# ------------------------------------------------------------------------------------------------ planes (split-bf16) storage
+def _pl(t):
+    return K.split_planes(t.contiguous().to(DEV))
+
+
+def test_planes_roundtrip_and_colsum():
+    x = rnd(300, 136)
+    p = _pl(x)
+    assert p.t.dtype == torch.bfloat16 and tuple(p.shape) == (300, 136)
+    close(p.float(), x, tol=2e-5, what="hi + lo ~ x (2^-17)")
+    assert float((p.t[0].float().cpu() - x.bfloat16().float()).abs().max()) == 0.0     # hi plane = round-to-nearest bf16
+    close(K.colsum(p, torch.empty(136, device=DEV)), x.sum(0), tol=2e-5, what="colsum planes")
+
+
+PL_GEMMS = [(200, 136, 72), (1024, 128, 768), (64, 256, 128), (512, 64, 264), (4096, 512, 512), (8192, 768, 256)]
+
+
+@pytest.mark.parametrize("M,N,Kd", PL_GEMMS)
+def test_planes_gemm_family(M, N, Kd, wide):
+    """Every GEMM form of the BERT path on planes operands (128x128-class tiles and, from 1 GFLOP with both dimensions >= 256,
+    the 256x256 LDS-DMA kernel) with every fused epilogue, against PyTorch-CPU fp32."""
+    x, w, b, r = rnd(M, Kd, scale=0.5), rnd(N, Kd, seed=1, scale=0.5), rnd(N, seed=2), rnd(M, N, seed=3)
+    xp, wp = _pl(x), _pl(w)
+    ref = x @ w.T
+    tol = 2e-4
+    close(K.linear_fwd_pl(xp, wp), ref, tol=tol, what="plain -> fp32")
+    close(K.linear_fwd_pl(xp, wp, out_planes=True).float(), ref, tol=tol, what="plain -> planes")
+    close(K.linear_fwd_pl(xp, wp, bias=b.to(DEV), residual=_pl(r)), ref + b + r, tol=tol, what="bias + planes residual -> fp32")
+    close(K.linear_fwd_pl(xp, wp, bias=b.to(DEV), residual=r.to(DEV)), ref + b + r, tol=tol, what="bias + fp32 residual -> fp32")
+    pre = torch.empty(M, N, device=DEV)
+    y = K.linear_fwd_pl(xp, wp, bias=b.to(DEV), act=K.ACT_GELU, preact_out=pre, out_planes=True)
+    close(y.float(), F.gelu(ref + b), tol=tol, what="gelu -> planes")
+    close(pre, ref + b, tol=tol, what="preact copy")
+    mask = torch.empty(M, N // 8, dtype=torch.uint8, device=DEV) if N % 64 == 0 else None
+    if mask is not None:
+        y = K.linear_fwd_pl(xp, wp, bias=b.to(DEV), act=K.ACT_RELU, out_planes=True, maskout=mask)
+        close(y.float(), F.relu(ref + b), tol=tol, what="relu -> planes")
+        dec = K.unpack_mask(mask, N)
+        assert bool((dec == (y.float().cpu() > 0)).all())
+    # data gradient forms
+    dy, aux = rnd(M, N, seed=4, scale=0.5), rnd(M, Kd, seed=5)
+    dyp = _pl(dy)
+    close(K.linear_bwd_data_pl(dyp, wp), dy @ w, tol=tol, what="dgrad -> fp32")
+    close(K.linear_bwd_data_pl(dyp, wp, residual=_pl(aux)), dy @ w + aux, tol=tol, what="dgrad + planes residual")
+    a = aux.clone().requires_grad_(True)
+    F.gelu(a).backward(dy @ w)
+    close(K.linear_bwd_data_pl(dyp, wp, aux=aux.to(DEV), auxmode=K.AUX_GELU_GRAD, out_planes=True).float(), a.grad, tol=tol, what="dgrad gelu'")
+    dec = (rnd(M, Kd, seed=6) > 0)
+    bits = torch.from_numpy(__import__("numpy").packbits(dec.numpy(), axis=1, bitorder="little")).to(DEV)
+    close(K.linear_bwd_data_pl(dyp, wp, maskin=bits, out_planes=True).float(), (dy @ w) * dec, tol=tol, what="dgrad bit mask")
+    out = torch.full((M, Kd), 1.0, device=DEV)
+    close(K.linear_bwd_data_pl(dyp, wp, out=out, accumulate=True), dy @ w + 1.0, tol=tol, what="dgrad accumulate")
+    # weight gradient (split-K)
+    dw = torch.zeros(N, Kd, device=DEV)
+    close(K.linear_bwd_weight_pl(dyp, xp, dw), dy.T @ x, tol=tol, what="wgrad")
+    close(K.linear_bwd_weight_pl(dyp, xp, dw, accumulate=True), 2 * (dy.T @ x), tol=tol, what="wgrad accumulate")
+
+
+def test_planes_gemm_strided_rows(wide):
+    h, w = rnd(16 * 32, 768), rnd(128, 768, seed=1)
+    hp = _pl(h)
+    cls = K.Planes(hp.t.view(2, 16, 32 * 768)[:, :, :768])        # CLS rows: row stride L*H
+    close(K.linear_fwd_pl(cls, _pl(w)), h.view(16, 32, 768)[:, 0] @ w.T, tol=2e-4, what="strided planes A")
+    dx = torch.zeros(16 * 32, 768, device=DEV)
+    dy = rnd(16, 128, seed=2)
+    K.linear_bwd_data_pl(_pl(dy), _pl(w), out=dx.view(16, 32 * 768)[:, :768], accumulate=True)
+    ref = torch.zeros(16, 32, 768)
+    ref[:, 0] = dy @ w
+    close(dx.view(16, 32, 768), ref, tol=2e-4, what="strided fp32 output rows")
+    K.planes_add_rows(_pl(dy @ w), dx.view(16, 32 * 768)[:, :768])
+    close(dx.view(16, 32, 768), 2 * ref, tol=2e-4, what="planes_add_rows")
+
+
+PL_CONVS = [  # N,H,W,C,Ko,R,stride,pad
+    (2, 14, 14, 64, 64, 1, 1, 0), (2, 14, 14, 64, 256, 1, 1, 0), (3, 9, 9, 128, 128, 3, 1, 1), (2, 14, 14, 128, 128, 3, 2, 1),
+    (2, 14, 14, 256, 512, 1, 2, 0), (2, 15, 15, 64, 128, 3, 2, 1), (2, 14, 14, 1024, 256, 1, 1, 0), (2, 7, 7, 512, 2048, 1, 1, 0),
+    (2, 56, 56, 256, 64, 1, 1, 0),
+    # >= 1 GFLOP: the 256x256 LDS-DMA kernel takes forward / data gradient / weight gradient where both tile dimensions fill
+    (16, 28, 28, 128, 128, 3, 1, 1), (32, 28, 28, 256, 256, 3, 2, 1), (64, 14, 14, 256, 1024, 1, 1, 0), (64, 14, 14, 1024, 256, 1, 1, 0),
+    (32, 28, 28, 512, 1024, 1, 2, 0),
+]
+
+
+@pytest.mark.parametrize("cfg", PL_CONVS)
+def test_planes_conv_bn_relu_fwd_bwd(cfg, wide):
+    """conv + BN + identity + ReLU forward (planes in / out, ReLU bit mask), data gradient (bit mask, residual, fused column sums)
+    and weight gradient (+ BN gradients) on planes operands against PyTorch-CPU fp32."""
+    N, H, W, C, Ko, R, stride, pad = cfg
+    x, w, gamma, beta, rm, rv = _conv_case(*cfg)
+    for t in (x, w, gamma, beta):
+        t.requires_grad_(True)
+    z = F.conv2d(x, w, stride=stride, padding=pad)
+    ybn = F.batch_norm(z, rm, rv, gamma, beta, training=False, eps=1e-5)
+    res = rnd(*ybn.shape, seed=9)
+    pre = ybn + res
+    Ho, Wo = pre.shape[2], pre.shape[3]
+    xd = _pl(x.detach().permute(0, 2, 3, 1))
+    w_cl = w.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    ws = K.Planes.empty(Ko, R * R * C, device=DEV)
+    sc, sh, rstd = (torch.empty(Ko, device=DEV) for _ in range(3))
+    g_, b_, rm_, rv_ = gamma.detach().to(DEV), beta.detach().to(DEV), rm.to(DEV), rv.to(DEV)
+    K.bn_fold_pl(w_cl, g_, b_, rm_, rv_, 1e-5, Ko, R * R, C, C, ws, sc, sh, rstd)
+    resd = _pl(res.permute(0, 2, 3, 1))
+    yd = K.Planes.empty(N, Ho, Wo, Ko, device=DEV)
+    mask = torch.empty(N * Ho * Wo, Ko // 8, dtype=torch.uint8, device=DEV)
+    K.conv_fwd_pl(xd, ws, sh, resd, yd, mask, N, H, W, C, Ko, R, R, stride, pad, True)
+    yf = yd.float()
+    dec = K.unpack_mask(mask, Ko).view(N, Ho, Wo, Ko)
+    assert bool((dec == (yf.cpu() > 0)).all())
+    dec_nchw = dec.permute(0, 3, 1, 2)
+    flips = dec_nchw != (pre.detach() > 0)
+    assert int(flips.sum()) <= max(8, flips.numel() // 20000) and (not flips.any() or float(pre.detach()[flips].abs().max() / pre.detach().abs().max()) < 2e-3)
+    y = pre * dec_nchw
+    gy = rnd(*y.shape, seed=10)
+    y.backward(gy)
+    close(K.nhwc_to_nchw(yf), y, tol=2e-4, what="planes conv fwd")
+    gyd = _pl((gy * dec_nchw).permute(0, 2, 3, 1))
+    sumdy = K.colsum(gyd.view(N * Ho * Wo, Ko), torch.empty(Ko, device=DEV))
+    dw, dg, db = torch.empty(Ko, R, R, C, device=DEV), torch.empty(Ko, device=DEV), torch.empty(Ko, device=DEV)
+    K.conv_bwd_params_pl(xd, gyd, w_cl, sc, rstd, rm_, sumdy, dw, dg, db, False, N, H, W, C, Ko, R, R, stride, pad)
+    close(dw.permute(0, 3, 1, 2), w.grad, tol=3e-4, what="planes conv wgrad")
+    close(dg, gamma.grad, tol=2e-2, what="planes bn dgamma")
+    close(db, beta.grad, tol=3e-4, what="planes bn dbeta")
+    dxd = K.Planes.empty(N, H, W, C, device=DEV)
+    K.conv_bwd_data_pl(gyd, ws, None, None, dxd, N, H, W, C, Ko, R, R, stride, pad)
+    close(K.nhwc_to_nchw(dxd.float()), x.grad, tol=3e-4, what="planes conv dgrad")
+    if not (R == 1 and stride == 2):
+        add = rnd(N, H, W, C, seed=11)
+        xdec = (rnd(N, H, W, C, seed=12) > 0)
+        bits = torch.from_numpy(__import__("numpy").packbits(xdec.view(-1, C).numpy(), axis=1, bitorder="little")).to(DEV)
+        sums = torch.empty(C, device=DEV)
+        K.conv_bwd_data_pl(gyd, ws, _pl(add), bits, dxd, N, H, W, C, Ko, R, R, stride, pad, sums=sums)
+        ref = (x.grad.permute(0, 2, 3, 1) + add) * xdec
+        close(dxd.float(), ref, tol=3e-4, what="planes dgrad + residual + bit mask")
+        close(sums, ref.double().reshape(-1, C).sum(0).float(), tol=3e-4, what="planes dgrad column sums")
+
+
+def test_planes_stem_maxpool_and_mean():
+    """stem (fp32 image -> planes), max-pool on planes (+ backward masked by the sign of the pooled value), mean backward."""
+    N, H, C, Ko = 2, 32, 4, 64
+    x, w, gamma, beta, rm, rv = _conv_case(N, H, H, C, Ko, 7, 2, 3, cin_real=3)
+    ybn = F.batch_norm(F.conv2d(x, w, stride=2, padding=3), rm, rv, gamma, beta, training=False, eps=1e-5)
+    xd = K.nchw_to_nhwc(x.to(DEV), 4)
+    w_cl = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ws = torch.empty(Ko, 7, 7, 4, device=DEV)
+    sc, sh, rstd = (torch.empty(Ko, device=DEV) for _ in range(3))
+    K.bn_fold(w_cl, gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), 1e-5, Ko, 49, 3, 4, ws, sc, sh, rstd)
+    yd = K.Planes.empty(N, 16, 16, Ko, device=DEV)
+    K.conv_fwd_pl(xd, ws, sh, None, yd, None, N, H, H, 4, Ko, 7, 7, 2, 3, True)
+    close(K.nhwc_to_nchw(yd.float()), F.relu(ybn), tol=2e-4, what="stem -> planes")
+    stem = yd.float().permute(0, 3, 1, 2).cpu().requires_grad_(True)       # continue from the device's own values
+    pooled_ref = F.max_pool2d(stem, 3, 2, 1)
+    gp = rnd(*pooled_ref.shape, seed=3)
+    pooled_ref.backward(gp)
+    pd, idx = K.maxpool_fwd_pl(yd)
+    assert float((K.nhwc_to_nchw(pd.float()).cpu() - pooled_ref.detach()).abs().max()) == 0.0
+    ds = K.maxpool_bwd_pl(_pl(gp.permute(0, 2, 3, 1)), idx, pd, 16, 16)
+    close(K.nhwc_to_nchw(ds), stem.grad * (stem.detach() > 0), tol=2e-5, what="maxpool bwd (+ stem ReLU)")
+    g, add = rnd(3, 128, seed=1), rnd(3, 49, 128, seed=2)
+    close(K.spatial_mean_bwd_pl(g.to(DEV), 49, add=add.to(DEV)).float(), (g / 49)[:, None, :] + add, tol=2e-5, what="spatial mean bwd -> planes")
 
 
 def test_maxpool_spatial_mean():
@@ -206,6 +392,11 @@ def test_layernorm_fwd_bwd(H):
     close(dx, s.grad + add, what="ln dx")
     close(dg, g.grad, what="ln dgamma")
     close(db, b.grad, what="ln dbeta")
+    if H % 8 == 0:   # planes outputs (what the next GEMM reads in split-bf16 mode)
+        yp, _, _ = K.residual_ln_fwd(x.to(DEV), r.to(DEV), g.detach().to(DEV), b.detach().to(DEV), 1e-12, out_planes=True)
+        close(yp.float(), y, what="ln fwd -> planes")
+        dxp = K.residual_ln_bwd(gy.to(DEV), xhat, rstd, g.detach().to(DEV), dg, db, out_planes=True)
+        close(dxp.float(), s.grad, what="ln dx -> planes")
 
 
 def test_embed_ln_and_scatter():
@@ -216,6 +407,8 @@ def test_embed_ln_and_scatter():
     ref = F.layer_norm(word[ids] + pos[:L][None] + typ[0], (H,), g, b, 1e-12)
     y, xhat, rstd = K.embed_ln_fwd(ids.to(DEV), word.to(DEV), pos.to(DEV), typ[0].contiguous().to(DEV), g.to(DEV), b.to(DEV), 1e-12, L)
     close(y.view(B, L, H), ref, what="embed ln")
+    yp, _, _ = K.embed_ln_fwd(ids.to(DEV), word.to(DEV), pos.to(DEV), typ[0].contiguous().to(DEV), g.to(DEV), b.to(DEV), 1e-12, L, out_planes=True)
+    close(yp.float().view(B, L, H), ref, what="embed ln -> planes")
     dx = rnd(B * L, H, seed=6)
     dword = torch.zeros(V, H, device=DEV)
     K.embed_bwd(ids.to(DEV).view(-1), dx.to(DEV), dword)
@@ -243,6 +436,9 @@ def test_attention_fwd_bwd(L, ragged):
     close(cd, ctx, what="attn fwd")
     dq = K.attn_bwd(qd, probs, gc.to(DEV), B, L, nH, dH)
     close(dq, qkv.grad, tol=5e-5, what="attn bwd")
+    cp, _ = K.attn_fwd(qd, mask.to(DEV), B, L, nH, dH, out_planes=True)
+    close(cp.float(), ctx, what="attn fwd -> planes")
+    close(K.attn_bwd(qd, probs, gc.to(DEV), B, L, nH, dH, out_planes=True).float(), qkv.grad, tol=5e-5, what="attn bwd -> planes")
 
 
 # ------------------------------------------------------------------------------------------------ heads
@@ -319,82 +515,12 @@ def test_adam_sgd_weight_reset():
 
 
 # ------------------------------------------------------------------------------------------------ 256x256 tile
-def _with_precision(mode):
-    import contextlib
-
-    @contextlib.contextmanager
-    def cm():
-        old = _cxr_lib.get_precision()
-        _cxr_lib.set_precision(mode)
-        try:
-            yield
-        finally:
-            _cxr_lib.set_precision(old)
-    return cm()
-
-
-def test_wide_tile_dense_at_policy_shapes():
-    """Shapes at which the library's OWN policy picks the 256x256 kernel in split-bf16 (`cxrk_gemm_wide_tile`), checked
-    against PyTorch-CPU fp32 and against the exact-fp32 mainloop of the same entry point: forward with a fused
-    bias + GELU + pre-activation copy, data gradient with a residual and a ReLU mask, weight gradient through split-K."""
+def test_wide_kernel_policy_at_step_shapes():
+    """The library's own policy (`cxrk_gemm_wide_tile`) sends the big BERT shapes to the 256x256 LDS-DMA kernel and keeps small /
+    narrow ones on the 128x128-class tiles (both kernels are checked on every test shape through the `wide` fixture)."""
     lib = _cxr_lib.load()
-    M, N, Kd = 4096, 4096, 512                      # 256 tiles = one full round of the 256 CUs
-    x, w, b = rnd(M, Kd, scale=0.5), rnd(N, Kd, seed=1, scale=0.5), rnd(N, seed=2)
-    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
-    with _with_precision("split_bf16"):
-        assert lib.cxrk_gemm_wide_tile(M, N, Kd, 1, 3) == 1 and lib.cxrk_gemm_wide_tile(M, N, Kd, 1, 0) == 1
-        pre = torch.empty(M, N, device=DEV)
-        y = K.linear_fwd(xd, wd, bias=bd, act=K.ACT_GELU, preact_out=pre)
-        ref = x @ w.T + b
-        close(pre, ref, tol=3e-4, what="wide fwd preact")
-        close(y, F.gelu(ref), tol=3e-4, what="wide fwd gelu")
-        dy, r, aux = rnd(M, N, seed=3, scale=0.5), rnd(M, Kd, seed=4), rnd(M, Kd, seed=5)
-        M2, N2, K2 = M, 4096, N                      # dx[M, 4096] = dy[M, N] @ w2[N, 4096]
-        w2 = rnd(N, N2, seed=6, scale=0.5)
-        r2, aux2 = rnd(M, N2, seed=7), rnd(M, N2, seed=8)
-        assert lib.cxrk_gemm_wide_tile(M2, N2, K2, 1, 3) == 1
-        dx = K.linear_bwd_data(dy.to(DEV), w2.to(DEV), aux=aux2.to(DEV), auxmode=K.AUX_RELU_MASK, residual=r2.to(DEV))
-        close(dx, (dy @ w2 + r2) * (aux2 > 0), tol=3e-4, what="wide dgrad")
-        # weight gradient: small output, long reduction -> split-K slabs on the wide tile
-        T, No, Ki = 32768, 1024, 768
-        g, a = rnd(T, No, seed=9, scale=0.3), rnd(T, Ki, seed=10, scale=0.3)
-        sk = lib.cxrk_gemm_wgrad_splitk(No, Ki, T)
-        assert sk > 1 and lib.cxrk_gemm_wide_tile(No, Ki, T, sk, 0) == 1
-        dw = torch.empty(No, Ki, device=DEV)
-        close(K.linear_bwd_weight(g.to(DEV), a.to(DEV), dw), g.T @ a, tol=3e-4, what="wide wgrad")
-        y_x3 = y.clone()
-    with _with_precision("fp32"):
-        close(y_x3, K.linear_fwd(xd, wd, bias=bd, act=K.ACT_GELU), tol=3e-4, what="wide vs exact fp32 mainloop")
-
-
-def test_wide_tile_conv_at_policy_shapes():
-    """3x3 convolution (256 -> 512 channels, 14x14, batch 136) at which the policy picks the 256x256 kernel for the
-    forward and for the weight gradient; reference = the exact-fp32 mainloop of the same entry points (itself checked
-    against PyTorch in test_conv_bn_relu_fwd_bwd)."""
-    lib = _cxr_lib.load()
-    N, H, C, Ko, R = 136, 14, 256, 512, 3
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(N, H, H, C, generator=g).to(DEV)
-    w = (torch.randn(Ko, R, R, C, generator=g) / math.sqrt(C * R * R)).to(DEV)
-    sh = (0.1 * torch.randn(Ko, generator=g)).to(DEV)
-    res = torch.randn(N, H, H, Ko, generator=g).to(DEV)
-    dy = torch.randn(N, H, H, Ko, generator=g).to(DEV)
-    sc = torch.ones(Ko, device=DEV); zero = torch.zeros(Ko, device=DEV)
-
-    def run():
-        y = torch.empty(N, H, H, Ko, device=DEV)
-        K.conv_fwd(x, w, sh, res, y, N, H, H, C, Ko, R, R, 1, 1, True)
-        dw = torch.empty_like(w); dg = torch.empty(Ko, device=DEV); db = torch.empty(Ko, device=DEV)
-        K.conv_bwd_params(x, dy, w, sc, sc, zero, zero, None, None, dw, dg, db, False, N, H, H, C, C, Ko, R, R, 1, 1)
-        return y, dw
-
-    with _with_precision("split_bf16"):
-        M = N * H * H
-        assert lib.cxrk_gemm_wide_tile(M, Ko, R * R * C, 1, 1) == 1
-        sk = lib.cxrk_gemm_wgrad_splitk(Ko, R * R * C, M)
-        assert lib.cxrk_gemm_wide_tile(Ko, R * R * C, M, sk, 0) == 1
-        y1, dw1 = run()
-    with _with_precision("fp32"):
-        y0, dw0 = run()
-    close(y1, y0, tol=3e-4, what="wide conv fwd vs exact fp32")
-    close(dw1, dw0, tol=3e-4, what="wide conv wgrad vs exact fp32")
+    assert lib.cxrk_gemm_wide_tile(32768, 3072, 768, 1, 3) == 1 and lib.cxrk_gemm_wide_tile(32768, 768, 3072, 1, 0) == 1
+    assert lib.cxrk_gemm_wide_tile(1024, 128, 768, 1, 0) == 0 and lib.cxrk_gemm_wide_tile(200, 136, 72, 1, 0) == 0
+    sk = lib.cxrk_gemm_wgrad_splitk(768, 3072, 32768, 1)
+    assert sk > 1 and lib.cxrk_gemm_wide_tile(768, 3072, 32768, sk, 0) == 1
+    assert lib.cxrk_gemm_wgrad_splitk(768, 3072, 32768, 0) >= 1

@@ -148,6 +148,8 @@ def test_image_model_forward_backward(golden_dir):
     # (1) rigorous gradient parity: oracle run under the same ReLU decisions -> every tensor within 1e-3
     _, gref, pol = _image_oracle_with_decisions(sd_cpu, x, probe, masks)
     assert pol.count > 5_000_000 and pol.flips <= _flip_budget()[0] and pol.max_flip_rel < _flip_budget()[1], (pol.flips, pol.max_flip_rel)
+    # max-pool winners: imposed like the ReLU decisions; they may differ from the oracle's own only at ties (values within rounding)
+    assert pol.pool_flips <= _flip_budget()[0] // 100 + 2 and pol.pool_max_gap < _flip_budget()[1], (pol.pool_flips, pol.pool_max_gap)
     worst = max(((rel(named[k].grad, v), k) for k, v in gref.items()), key=lambda t: t[0])
     assert worst[0] < TOL, worst
     # (2) against the committed fixture (oracle's own decisions): a kink flip moves upstream gradients by ~1e-3,
@@ -165,6 +167,24 @@ def test_image_model_forward_backward(golden_dir):
     assert rel(patches.norm(dim=-1), torch.ones(2, 7, 7)) < 1e-5
     model.freeze_encoder = True
     assert not model(x.to(DEV)).requires_grad
+
+
+def test_reference_pinned_image_fixtures_through_the_hip_path(golden_dir):
+    """The vectors of g3_image.npz that were produced by the reference's OWN code (modules.MLP on `proj_patch_in`) and the
+    oracle's trunk checksums go through the HIP kernels directly, not only through the oracle."""
+    g = np.load(f"{golden_dir}/g3_image.npz")
+    model = get_biovil_resnet(None)
+    syn.fill_module_(model)
+    model.to(DEV).eval()
+    out = model.project_patch_embeddings(T(g["proj_patch_in"]).to(DEV))          # reference modules.MLP output
+    assert rel(out, g["proj_patch_out"]) < TOL, rel(out, g["proj_patch_out"])
+    stages = model.forward_stages(syn.synthetic_images(2, 224, seed=27).to(DEV))
+    assert len(stages) == 5
+    for i, st in enumerate(stages):
+        n = st.numel()
+        assert abs(float(st.double().sum()) - float(g[f"stage{i}_sum"])) / (float(g[f"stage{i}_absmean"]) * n) < 1e-5, i
+        assert abs(float(st.abs().mean()) - float(g[f"stage{i}_absmean"])) / float(g[f"stage{i}_absmean"]) < TOL, i
+        assert rel(st[:, :4, :3, :3], g[f"stage{i}_corner"]) < TOL, (i, rel(st[:, :4, :3, :3], g[f"stage{i}_corner"]))
 
 
 def test_image_model_rejects_cpu_and_bad_input():
@@ -212,6 +232,14 @@ def test_adapter_step_vs_reference_models(golden_dir):
     lin = myLinearModel()
     syn.fill_module_(lin, "dense_adapter.")
     assert rel(lin.to(DEV)(embs), g["dense_out"]) < TOL
+    # eval scoring (Trainer.py:825-836) of the step-3 adapters against the fixture written from the reference's models
+    from incremental_multimodal_medical_learning_ii_amd import kernels as K
+    with torch.no_grad():
+        pv = Fh.group_mean(txt_ad(bert_out.reshape(40, 128)), 10, 4)
+        cosv = Fh.pairwise_cosine_similarity(img_ad(embs), pv)
+        score, pred = K.eval_score(cosv.contiguous())
+    assert rel(score, g["eval_score"]) < TOL
+    assert float((pred.cpu() == T(g["eval_pred"])).float().mean()) > 0.999
 
 
 def test_infonce_and_zeroshot(golden_dir):
@@ -281,11 +309,17 @@ def test_joint_step_vs_cpu_oracle():
             worst = (n, e)
     assert worst[1] < TOL, worst
     isd, tsd = im.state_dict(), tm.state_dict()
-    ptol = TOL if _cxr_lib.get_precision() == "fp32" else 3e-3   # Adam's first step is ~lr*sign(g): entries with g ~ 0 amplify
+    # Adam's first step moves a weight by ~lr*sign(g): an entry whose gradient is ~0 may take the other sign in two correct
+    # implementations (|difference| = 2 lr).  The bar is therefore on the 99.9th percentile of the error; the maximum is only bounded
+    # by a few such sign steps.
+    def rel_q(a, b, q=0.999):
+        d = (a.detach().float().cpu() - b.detach().float().cpu()).abs().flatten()
+        v_ = d.kthvalue(max(1, int(q * d.numel()))).values if d.numel() > 1 else d.max()
+        return float(v_ / b.detach().float().abs().max().clamp_min(1e-30))
     for d, sd in ((ip, isd), (tp, tsd)):
         for k, v in d.items():
             if v.requires_grad:
-                assert rel(sd[k], v) < ptol, k
+                assert rel_q(sd[k], v) < TOL and rel(sd[k], v) < 5e-3, k
 
 
 def test_text_cls_only_last_layer_equals_full_path():
