@@ -161,6 +161,25 @@ def selftest_rank() -> None:
     dist.destroy_process_group()
 
 
+def structured_images(batch: int, size: int, seed: int) -> torch.Tensor:
+    """Synthetic 1-channel images replicated to 3 channels (reference: DataRetrieval.py:175-180) with per-image low-frequency
+    structure (a few random plane waves + noise, scaled into [0,1)), so that different images get different embeddings and the
+    contrastive loss has something to separate; iid-noise images (synthetic.synthetic_images, used by the parity fixtures) all map
+    to nearly the same embedding and pin the loss at ln(batch)."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, size), torch.linspace(0, 1, size), indexing="ij")
+    img = torch.zeros(batch, size, size)
+    for _ in range(4):
+        f = torch.rand(batch, 2, generator=g) * 6.0
+        ph = torch.rand(batch, 1, 1, generator=g) * 6.2832
+        amp = torch.rand(batch, 1, 1, generator=g)
+        img += amp * torch.cos(6.2832 * (f[:, 0, None, None] * yy + f[:, 1, None, None] * xx) + ph)
+    img += 0.25 * torch.randn(batch, size, size, generator=g)
+    img -= img.amin(dim=(1, 2), keepdim=True)
+    img /= img.amax(dim=(1, 2), keepdim=True).clamp_min(1e-6) * 1.0001
+    return img.unsqueeze(1).repeat_interleave(3, dim=1).contiguous()
+
+
 def secondary_metrics(args, dev, trainer, images, ids, mask, step_ms):
     """SURVEY.md §8(d) / BASELINE.md §3 side measurements (N = 1 only; none of them is `value`)."""
     from incremental_multimodal_medical_learning_ii_amd import functional as Fh
@@ -265,7 +284,7 @@ def main():
     NB = 4                                      # resident batches the steps rotate through
     batches = []
     for j in range(NB):
-        img = syn.synthetic_images(B, args.image_size, seed=27 + 101 * j + rank).to(dev)
+        img = structured_images(B, args.image_size, seed=27 + 101 * j + rank).to(dev)
         ids, mask = syn.synthetic_tokens(B, args.seq_len, seed=28 + 101 * j + rank)
         batches.append((img, ids.to(dev), mask.to(dev)))
     images, ids, mask = batches[0]

@@ -178,6 +178,12 @@ int cxrk_gelu_bwd(const float* dy, const float* pre, long n, float* dx, hipStrea
  *              row_lse gives lse + diagonal (+ accumulates sum(lse-diag)*scale into loss_out);
  *              grad_inplace turns S into exp(S-lse_row[i]) + exp(S-lse_col[j]) - 2*[j==diag_off+i].
  * pairwise_cosine: torchmetrics pairwise_cosine_similarity as called by Trainer.myCosineSimilarity (Trainer.py:1682-1704).
+ * pairwise_cosine_max: the MAX_EMB branch of the same function (Trainer.py:1691-1693): y holds G groups of Pg prompt
+ *              vectors (group g = rows g*Pg .. g*Pg+Pg-1); besides cos [B][G*Pg] it returns, per image and group, the maximum
+ *              over the group's prompts (first winner on ties, as torch.max), the mean (logged at Trainer.py:1697-1703) and
+ *              the winner's index, which max_bwd uses to route dmax [B][G] to one prompt per group.
+ * patch_similarity: sim[r] = <patches[r,:], text> — `projected_patch_embeddings.view(-1, D) @ text.t()`
+ *              (health_multimodal/vlp/inference_engine.py:104); smoothing and resizing stay on the host.
  * bce_posneg:  logits = cos_pos - cos_neg (Trainer.py:575) + nn.BCEWithLogitsLoss() mean (ZERO_JOINT_BOUNDS.py:36);
  *              cos is [B][2C] with column 2c = positive prompt of class c, 2c+1 = negative; writes dloss/dcos.
  * eval_score:  Trainer.val/test scoring (Trainer.py:825-836).
@@ -196,6 +202,12 @@ size_t cxrk_pairwise_cosine_bwd_ws_bytes(long B, int P, int D);
 int cxrk_pairwise_cosine_bwd(const float* x, const float* y, const float* cosv, const float* dcos, const float* xnorm,
                              const float* ynorm, long B, int P, int D, float* dx, float* dy, int accumulate_dy,
                              float* ws, size_t ws_bytes, hipStream_t stream);
+int cxrk_pairwise_cosine_max_fwd(const float* x, const float* y, long B, int G, int Pg, int D, float* cosv, float* xnorm,
+                                 float* ynorm, float* maxv, float* meanv, int* argmax, hipStream_t stream);
+int cxrk_pairwise_cosine_max_bwd(const float* x, const float* y, const float* cosv, const float* dmax, const int* argmax,
+                                 const float* xnorm, const float* ynorm, long B, int G, int Pg, int D, float* dx, float* dy,
+                                 int accumulate_dy, float* ws, size_t ws_bytes, hipStream_t stream);
+int cxrk_patch_similarity(const float* patches, const float* text, long R, int D, float* sim, hipStream_t stream);
 size_t cxrk_bce_posneg_ws_bytes(void);
 int cxrk_bce_posneg_fwd_bwd(const float* cosv, const float* labels, long B, int C, int ldlab, int diff, float* logits,
                             float* dcos, float* loss, float* ws, size_t ws_bytes, hipStream_t stream);

@@ -406,16 +406,16 @@ class Trainer:
                 return Fh.pairwise_cosine_similarity(x.reshape(1, -1), y.reshape(1, -1))
             if not MAX_EMB:
                 return Fh.pairwise_cosine_similarity(x, y.reshape(1, -1))
-            res = Fh.pairwise_cosine_similarity(x, y)
-            res_mean = torch.mean(res, dim=1)
-            res, _ = torch.max(res, dim=1)
+            res, res_mean, _ = Fh.pairwise_cosine_max(x, y.reshape(-1, x.shape[1]), 1)
+            res, res_mean = res.reshape(-1), res_mean.reshape(-1)
             if train and self.writer is not None:
+                gap = float((res.detach().double() - res_mean.double()).mean())   # one scalar for the log, off the gradient path
                 if pos:
                     self.pos_mean_counter += 1
-                    self.writer.add_scalar("max-mean-comparison/pos", torch.mean(res - res_mean), self.pos_mean_counter)
+                    self.writer.add_scalar("max-mean-comparison/pos", gap, self.pos_mean_counter)
                 else:
                     self.neg_mean_counter += 1
-                    self.writer.add_scalar("max-mean-comparison/neg", torch.mean(res - res_mean), self.neg_mean_counter)
+                    self.writer.add_scalar("max-mean-comparison/neg", gap, self.neg_mean_counter)
             return res
 
     def _prompt_matrix(self, class_names: Sequence[str], use_grad: bool) -> torch.Tensor:
@@ -435,14 +435,25 @@ class Trainer:
             e = torch.cat(groups, dim=0)
             if self._has_txt:
                 e = self.text_adapter(e)
+            if MAX_EMB:
+                return e   # [2C*n,128]: the max over each group's n prompts is taken on the cosines (`Trainer.py:1691-1693`)
             return Fh.group_mean(e, len(groups), n) if n > 1 else e
 
     def _logits_and_loss(self, new_embs, labels, class_names, criterion, use_grad):
         """logits [B,C] (+ loss).  Fast path: fused cosine + BCE kernels; otherwise the reference's per-class loop."""
-        pm = None if MAX_EMB else self._prompt_matrix(class_names, use_grad)
+        pm = self._prompt_matrix(class_names, use_grad)
         with torch.set_grad_enabled(use_grad):
             if pm is not None:
-                cos = Fh.pairwise_cosine_similarity(new_embs, pm)
+                if MAX_EMB:
+                    cos, cos_mean, _ = Fh.pairwise_cosine_max(new_embs, pm, 2 * len(class_names))
+                    if use_grad and self.writer is not None:   # the reference's per-call log (`Trainer.py:1694-1703`)
+                        gap = (cos.detach().double() - cos_mean.double()).mean(0).tolist()
+                        for g, v in enumerate(gap):
+                            tag, ctr = ("pos", "pos_mean_counter") if g % 2 == 0 else ("neg", "neg_mean_counter")
+                            setattr(self, ctr, getattr(self, ctr) + 1)
+                            self.writer.add_scalar("max-mean-comparison/" + tag, v, getattr(self, ctr))
+                else:
+                    cos = Fh.pairwise_cosine_similarity(new_embs, pm)
                 fused = (type(criterion) is nn.BCEWithLogitsLoss and criterion.weight is None
                          and criterion.pos_weight is None and criterion.reduction == "mean" and not self.change_labels)
                 if fused:

@@ -60,6 +60,9 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_pairwise_cosine_fwd": (I, [P, P, L, I, I, P, P, P, P]),
     "cxrk_pairwise_cosine_bwd_ws_bytes": (Z, [L, I, I]),
     "cxrk_pairwise_cosine_bwd": (I, [P, P, P, P, P, P, L, I, I, P, P, I, P, Z, P]),
+    "cxrk_pairwise_cosine_max_fwd": (I, [P, P, L, I, I, I, P, P, P, P, P, P, P]),
+    "cxrk_pairwise_cosine_max_bwd": (I, [P, P, P, P, P, P, P, L, I, I, I, P, P, I, P, Z, P]),
+    "cxrk_patch_similarity": (I, [P, P, L, I, P, P]),
     "cxrk_bce_posneg_ws_bytes": (Z, []),
     "cxrk_bce_posneg_fwd_bwd": (I, [P, P, L, I, I, I, P, P, P, P, Z, P]),
     "cxrk_eval_score": (I, [P, L, I, I, P, P, P]),

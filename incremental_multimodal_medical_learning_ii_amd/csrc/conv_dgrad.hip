@@ -69,12 +69,15 @@ static int conv_bwd_data_impl(const typename FMT::T* dy, long dyplane, const typ
   if (stride == 1) {
     if (use_wide256(M, C, K, 1, FMT::PLANES, WIDE_MINK_DGRAD)) {
       if constexpr (FMT::PLANES) {
-        DmaConvDgradKC::P pa{dy, g, M, K, dyplane}; DmaConvFilterMC::P pb{w, g, C, K, wplane};
-        rc = launch_gemm_pw<DmaConvDgradKC, DmaConvFilterMC>(pa, pb, ep, M, C, K, 1, stream);
+        DmaConvDgradKC<256, 8>::P pa{dy, g, M, K, dyplane}; DmaConvFilterMC<256, 8>::P pb{w, g, C, K, wplane};
+        rc = launch_gemm_pw<Pw256, DmaConvDgradKC<256, 8>, DmaConvFilterMC<256, 8>>(pa, pb, ep, M, C, K, 1, stream);
       } else return CXRK_ERR_UNSUPPORTED;
     } else if (C <= 64) {
       typename ConvDgradKC<256, FMT>::P pa{dy, g, M, K, dyplane}; typename ConvFilterMC<64, FMT>::P pb{w, g, C, K, wplane};
       rc = launch_gemm<ConvDgradKC<256, FMT>, ConvFilterMC<64, FMT>, 4, 1>(pa, pb, ep, M, C, K, 1, stream);
+    } else if constexpr (FMT::PLANES) {
+      DmaConvDgradKC<128, 4>::P pa{dy, g, M, K, dyplane}; DmaConvFilterMC<128, 4>::P pb{w, g, C, K, wplane};
+      rc = launch_gemm_pw<Pw128, DmaConvDgradKC<128, 4>, DmaConvFilterMC<128, 4>>(pa, pb, ep, M, C, K, 1, stream);
     } else {
       typename ConvDgradKC<128, FMT>::P pa{dy, g, M, K, dyplane}; typename ConvFilterMC<128, FMT>::P pb{w, g, C, K, wplane};
       rc = launch_gemm<ConvDgradKC<128, FMT>, ConvFilterMC<128, FMT>, 2, 2>(pa, pb, ep, M, C, K, 1, stream);
@@ -113,12 +116,15 @@ static int conv_bwd_data_impl(const typename FMT::T* dy, long dyplane, const typ
         e2.rm_on = 1; e2.rm_Hs = Hs; e2.rm_Ws = Ws; e2.rm_H = H; e2.rm_W = W; e2.rm_ph = ph; e2.rm_pw = pw;
         if (use_wide256(Ms, C, Ks, 1, FMT::PLANES, WIDE_MINK_DGRAD)) {
           if constexpr (FMT::PLANES) {
-            DmaConvDgradS2KC::P pa{dy, g, t, Hs, Ws, Ms, Ks, dyplane}; DmaConvFilterS2MC::P pb{w, g, t, C, Ks, wplane};
-            rc = launch_gemm_pw<DmaConvDgradS2KC, DmaConvFilterS2MC>(pa, pb, e2, Ms, C, Ks, 1, stream);
+            DmaConvDgradS2KC<256, 8>::P pa{dy, g, t, Hs, Ws, Ms, Ks, dyplane}; DmaConvFilterS2MC<256, 8>::P pb{w, g, t, C, Ks, wplane};
+            rc = launch_gemm_pw<Pw256, DmaConvDgradS2KC<256, 8>, DmaConvFilterS2MC<256, 8>>(pa, pb, e2, Ms, C, Ks, 1, stream);
           } else return CXRK_ERR_UNSUPPORTED;
         } else if (C <= 64) {
           typename ConvDgradS2KC<256, FMT>::P pa{dy, g, t, Hs, Ws, Ms, Ks, dyplane}; typename ConvFilterS2MC<64, FMT>::P pb{w, g, t, C, Ks, wplane};
           rc = launch_gemm<ConvDgradS2KC<256, FMT>, ConvFilterS2MC<64, FMT>, 4, 1>(pa, pb, e2, Ms, C, Ks, 1, stream);
+        } else if constexpr (FMT::PLANES) {
+          DmaConvDgradS2KC<128, 4>::P pa{dy, g, t, Hs, Ws, Ms, Ks, dyplane}; DmaConvFilterS2MC<128, 4>::P pb{w, g, t, C, Ks, wplane};
+          rc = launch_gemm_pw<Pw128, DmaConvDgradS2KC<128, 4>, DmaConvFilterS2MC<128, 4>>(pa, pb, e2, Ms, C, Ks, 1, stream);
         } else {
           typename ConvDgradS2KC<128, FMT>::P pa{dy, g, t, Hs, Ws, Ms, Ks, dyplane}; typename ConvFilterS2MC<128, FMT>::P pb{w, g, t, C, Ks, wplane};
           rc = launch_gemm<ConvDgradS2KC<128, FMT>, ConvFilterS2MC<128, FMT>, 2, 2>(pa, pb, e2, Ms, C, Ks, 1, stream);

@@ -20,13 +20,16 @@ static int conv_fwd_impl(const typename FMT::T* x, long xplane, const typename F
   const bool tapwise = (C % BK == 0) && R * S <= 32 && R <= 8;  // a K-tile inside one filter tap (everything but the stem)
   if (tapwise && use_wide256(M, Ko, K, 1, FMT::PLANES, WIDE_MINK_FPROP)) {
     if constexpr (FMT::PLANES) {
-      DmaConvIm2colKC::P pa{x, g, M, K, xplane}; DmaDenseKC::P pb{w, (long)K, Ko, K, wplane};
-      rc = launch_gemm_pw<DmaConvIm2colKC, DmaDenseKC>(pa, pb, ep, M, Ko, K, 1, stream);
+      DmaConvIm2colKC<256, 8>::P pa{x, g, M, K, xplane}; DmaDenseKC<256, 8>::P pb{w, (long)K, Ko, K, wplane};
+      rc = launch_gemm_pw<Pw256, DmaConvIm2colKC<256, 8>, DmaDenseKC<256, 8>>(pa, pb, ep, M, Ko, K, 1, stream);
     } else return CXRK_ERR_UNSUPPORTED;
   } else if (tapwise) {
     if (Ko <= 64) {
       typename ConvIm2colKC<256, FMT>::P pa{x, g, M, K, xplane}; typename DenseKC<64, FMT>::P pb{w, (long)K, Ko, K, wplane};
       rc = launch_gemm<ConvIm2colKC<256, FMT>, DenseKC<64, FMT>, 4, 1>(pa, pb, ep, M, Ko, K, 1, stream);
+    } else if constexpr (FMT::PLANES) {
+      DmaConvIm2colKC<128, 4>::P pa{x, g, M, K, xplane}; DmaDenseKC<128, 4>::P pb{w, (long)K, Ko, K, wplane};
+      rc = launch_gemm_pw<Pw128, DmaConvIm2colKC<128, 4>, DmaDenseKC<128, 4>>(pa, pb, ep, M, Ko, K, 1, stream);
     } else {
       typename ConvIm2colKC<128, FMT>::P pa{x, g, M, K, xplane}; typename DenseKC<128, FMT>::P pb{w, (long)K, Ko, K, wplane};
       rc = launch_gemm<ConvIm2colKC<128, FMT>, DenseKC<128, FMT>, 2, 2>(pa, pb, ep, M, Ko, K, 1, stream);

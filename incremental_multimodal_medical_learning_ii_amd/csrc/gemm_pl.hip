@@ -4,14 +4,24 @@
 
 using namespace cxrk;
 
-template <template <int, class, int> class LAT, template <int, class, int> class LBT, class DLA, class DLB>
+template <template <int, class, int> class LAT, template <int, class, int> class LBT, template <int, int> class DLA,
+          template <int, int> class DLB>
 static int dense_planes(const unsigned short* A, long lda, long aplane, const unsigned short* B, long ldb, long bplane, const EpiParams& ep,
                         int M, int N, int K, int splitk, hipStream_t stream) {
   if (use_wide256(M, N, K, splitk, true)) {
-    typename DLA::P pa{A, lda, M, K, aplane}; typename DLB::P pb{B, ldb, N, K, bplane};
-    return launch_gemm_pw<DLA, DLB>(pa, pb, ep, M, N, K, splitk, stream);
+    typename DLA<256, 8>::P pa{A, lda, M, K, aplane}; typename DLB<256, 8>::P pb{B, ldb, N, K, bplane};
+    return launch_gemm_pw<Pw256, DLA<256, 8>, DLB<256, 8>>(pa, pb, ep, M, N, K, splitk, stream);
   }
-  return dense_small<PL, LAT, LBT>(A, lda, aplane, B, ldb, bplane, ep, M, N, K, splitk, stream);
+  if (N <= 64) {
+    typename LAT<256, PL, NTHREADS>::P pa{A, lda, M, K, aplane}; typename LBT<64, PL, NTHREADS>::P pb{B, ldb, N, K, bplane};
+    return launch_gemm<LAT<256, PL, NTHREADS>, LBT<64, PL, NTHREADS>, 4, 1>(pa, pb, ep, M, N, K, splitk, stream);
+  }
+  if (M <= 64) {
+    typename LAT<64, PL, NTHREADS>::P pa{A, lda, M, K, aplane}; typename LBT<256, PL, NTHREADS>::P pb{B, ldb, N, K, bplane};
+    return launch_gemm<LAT<64, PL, NTHREADS>, LBT<256, PL, NTHREADS>, 1, 4>(pa, pb, ep, M, N, K, splitk, stream);
+  }
+  typename DLA<128, 4>::P pa{A, lda, M, K, aplane}; typename DLB<128, 4>::P pb{B, ldb, N, K, bplane};
+  return launch_gemm_pw<Pw128, DLA<128, 4>, DLB<128, 4>>(pa, pb, ep, M, N, K, splitk, stream);
 }
 
 // Same contraction on pre-split ("planes") operands: A and B are bf16 hi/lo plane pairs (lo plane `aplane` / `bplane` elements

@@ -91,7 +91,9 @@ __global__ void lse_loss_kernel(const float* __restrict__ lse, const float* __re
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pairwise_cosine_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                   long B, int P, int D, float* __restrict__ cosv,
-                                                                  float* __restrict__ xnorm, float* __restrict__ ynorm) {
+                                                                  float* __restrict__ xnorm, float* __restrict__ ynorm, int Pg,
+                                                                  float* __restrict__ maxv, float* __restrict__ meanv,
+                                                                  int* __restrict__ argmax) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B) return;
   const int lane = threadIdx.x & 63;
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(256) void pairwise_cosine_fwd_kernel(const float* _
   for (int i = 0; i < NV; ++i) { const int c = lane + i * 64; v[i] = c < D ? x[row * D + c] : 0.f; q += v[i] * v[i]; }
   const float xn = sqrtf(wave_sum(q));
   if (lane == 0) xnorm[row] = xn;
+  float gmax = 0.f, gsum = 0.f; int gidx = 0;
   for (int p = 0; p < P; ++p) {
     float d = 0.f, yy = 0.f;
 #pragma unroll
@@ -109,8 +112,30 @@ __global__ __launch_bounds__(256) void pairwise_cosine_fwd_kernel(const float* _
       d += v[i] * w; yy += w * w;
     }
     d = wave_sum(d); yy = sqrtf(wave_sum(yy));
-    if (lane == 0) { cosv[row * P + p] = (d / xn) / yy; if (row == 0) ynorm[p] = yy; }
+    const float c = (d / xn) / yy;
+    if (lane == 0) { cosv[row * P + p] = c; if (row == 0) ynorm[p] = yy; }
+    if (Pg > 0) {   // max (first winner, torch.max on ties) and mean over the Pg prompts of group p / Pg  (Trainer.py:1691-1693)
+      const int j = p % Pg;
+      if (j == 0) { gmax = c; gsum = c; gidx = 0; }
+      else { gsum += c; if (c > gmax || (c != c && gmax == gmax)) { gmax = c; gidx = j; } }
+      if (j == Pg - 1 && lane == 0) {
+        const long o = row * (P / Pg) + p / Pg;
+        maxv[o] = gmax; meanv[o] = gsum / (float)Pg; argmax[o] = gidx;
+      }
+    }
   }
+}
+
+// sim[r] = <patch_r, text>: the patch-wise similarity GEMV of vlp/inference_engine.py:104 (one wave per patch row).
+__global__ __launch_bounds__(256) void rows_dot_kernel(const float* __restrict__ x, const float* __restrict__ t, long R, int D,
+                                                       float* __restrict__ out) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int lane = threadIdx.x & 63;
+  float d = 0.f;
+  for (int c = lane; c < D; c += 64) d += x[row * D + c] * t[c];
+  d = wave_sum(d);
+  if (lane == 0) out[row] = d;
 }
 
 // dx_i = sum_p dc[i][p] * (yhat_p - cos*xhat_i)/|x_i| ; dy partial[blk][p] = sum_{i in blk} dc * (xhat_i - cos*yhat_p)/|y_p|
@@ -118,7 +143,8 @@ __global__ __launch_bounds__(256) void pairwise_cosine_bwd_kernel(const float* _
                                                                   const float* __restrict__ cosv, const float* __restrict__ dcos,
                                                                   const float* __restrict__ xnorm, const float* __restrict__ ynorm,
                                                                   long B, int P, int D, int rows_per, float* __restrict__ dx,
-                                                                  float* __restrict__ dy_part) {
+                                                                  float* __restrict__ dy_part, int Pg,
+                                                                  const int* __restrict__ argmax) {
   extern __shared__ float sm[];  // [4 waves][P][D]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float* mine = sm + (long)w * P * D;
@@ -130,7 +156,10 @@ __global__ __launch_bounds__(256) void pairwise_cosine_bwd_kernel(const float* _
 #pragma unroll
     for (int i = 0; i < NV; ++i) { const int c = lane + i * 64; xh[i] = c < D ? x[row * D + c] * ixn : 0.f; acc[i] = 0.f; }
     for (int p = 0; p < P; ++p) {
-      const float dc = dcos[row * P + p], cs = cosv[row * P + p];
+      float dc;   // Pg > 0: dcos is [B, P / Pg], the gradient of the group maximum, routed to the winner only
+      if (Pg > 0) { const long o = row * (P / Pg) + p / Pg; dc = argmax[o] == p % Pg ? dcos[o] : 0.f; }
+      else dc = dcos[row * P + p];
+      const float cs = cosv[row * P + p];
       const float iyn = 1.0f / ynorm[p];
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -281,7 +310,24 @@ extern "C" int cxrk_infonce_grad_inplace(float* S, long ld, int rows, int cols, 
 extern "C" int cxrk_pairwise_cosine_fwd(const float* x, const float* y, long B, int P, int D, float* cosv, float* xnorm,
                                         float* ynorm, hipStream_t stream) {
   CXRK_CHECK_ARG(x && y && cosv && xnorm && ynorm && B > 0 && P > 0 && D > 0 && D <= 64 * NV);
-  hipLaunchKernelGGL(pairwise_cosine_fwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, x, y, B, P, D, cosv, xnorm, ynorm);
+  hipLaunchKernelGGL(pairwise_cosine_fwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, x, y, B, P, D, cosv, xnorm, ynorm,
+                     0, nullptr, nullptr, nullptr);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+
+extern "C" int cxrk_patch_similarity(const float* patches, const float* text, long R, int D, float* sim, hipStream_t stream) {
+  CXRK_CHECK_ARG(patches && text && sim && R > 0 && D > 0);
+  hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, stream, patches, text, R, D, sim);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+
+extern "C" int cxrk_pairwise_cosine_max_fwd(const float* x, const float* y, long B, int G, int Pg, int D, float* cosv, float* xnorm,
+                                            float* ynorm, float* maxv, float* meanv, int* argmax, hipStream_t stream) {
+  CXRK_CHECK_ARG(x && y && cosv && xnorm && ynorm && maxv && meanv && argmax && B > 0 && G > 0 && Pg > 0 && D > 0 && D <= 64 * NV);
+  hipLaunchKernelGGL(pairwise_cosine_fwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, x, y, B, G * Pg, D, cosv, xnorm,
+                     ynorm, Pg, maxv, meanv, argmax);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
 }
@@ -289,23 +335,38 @@ extern "C" int cxrk_pairwise_cosine_fwd(const float* x, const float* y, long B, 
 static int cos_bwd_blocks(long B) { long nb = (B + 63) / 64; if (nb > 512) nb = 512; if (nb < 1) nb = 1; return (int)nb; }
 extern "C" size_t cxrk_pairwise_cosine_bwd_ws_bytes(long B, int P, int D) { return (size_t)cos_bwd_blocks(B) * P * D * sizeof(float); }
 
-extern "C" int cxrk_pairwise_cosine_bwd(const float* x, const float* y, const float* cosv, const float* dcos,
-                                        const float* xnorm, const float* ynorm, long B, int P, int D, float* dx, float* dy,
-                                        int accumulate_dy, float* ws, size_t ws_bytes, hipStream_t stream) {
+static int cosine_bwd(const float* x, const float* y, const float* cosv, const float* dcos, const float* xnorm, const float* ynorm, long B,
+                      int P, int D, float* dx, float* dy, int accumulate_dy, float* ws, size_t ws_bytes, int Pg, const int* argmax,
+                      hipStream_t stream) {
   CXRK_CHECK_ARG(x && y && cosv && dcos && xnorm && ynorm && dy && B > 0 && P > 0 && D > 0 && D <= 64 * NV);
-  const size_t sh = (size_t)4 * P * D * sizeof(float);
-  if (sh > 64 * 1024) return CXRK_ERR_UNSUPPORTED;
+  const size_t sh = (size_t)4 * P * D * sizeof(float);   // one [P][D] accumulator per wave
+  if (sh > 128 * 1024) return CXRK_ERR_UNSUPPORTED;
+  if (sh > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(pairwise_cosine_bwd_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) return CXRK_ERR_LAUNCH;
   int nb = cos_bwd_blocks(B);
   if (ws == nullptr || ws_bytes < (size_t)nb * P * D * sizeof(float)) return CXRK_ERR_WS;
   const int rows_per = (int)((B + nb - 1) / nb);
   nb = (int)((B + rows_per - 1) / rows_per);
   hipLaunchKernelGGL(pairwise_cosine_bwd_kernel, dim3(nb), dim3(256), sh, stream, x, y, cosv, dcos, xnorm, ynorm, B, P, D,
-                     rows_per, dx, ws);
+                     rows_per, dx, ws, Pg, argmax);
   CXRK_LAUNCH_CHECK();
   const long n = (long)P * D;
   hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ws, nb, n, dy, accumulate_dy);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
+}
+
+extern "C" int cxrk_pairwise_cosine_bwd(const float* x, const float* y, const float* cosv, const float* dcos,
+                                        const float* xnorm, const float* ynorm, long B, int P, int D, float* dx, float* dy,
+                                        int accumulate_dy, float* ws, size_t ws_bytes, hipStream_t stream) {
+  return cosine_bwd(x, y, cosv, dcos, xnorm, ynorm, B, P, D, dx, dy, accumulate_dy, ws, ws_bytes, 0, nullptr, stream);
+}
+
+extern "C" int cxrk_pairwise_cosine_max_bwd(const float* x, const float* y, const float* cosv, const float* dmax, const int* argmax,
+                                            const float* xnorm, const float* ynorm, long B, int G, int Pg, int D, float* dx, float* dy,
+                                            int accumulate_dy, float* ws, size_t ws_bytes, hipStream_t stream) {
+  CXRK_CHECK_ARG(argmax && G > 0 && Pg > 0);
+  return cosine_bwd(x, y, cosv, dmax, xnorm, ynorm, B, G * Pg, D, dx, dy, accumulate_dy, ws, ws_bytes, Pg, argmax, stream);
 }
 
 extern "C" size_t cxrk_bce_posneg_ws_bytes(void) { return 256 * sizeof(float); }

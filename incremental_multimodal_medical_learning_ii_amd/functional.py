@@ -119,6 +119,28 @@ def pairwise_cosine_similarity(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor
     return _PairwiseCosine.apply(x, y)
 
 
+class _PairwiseCosineMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, groups):
+        xd, yd = x.detach().contiguous(), y.detach().contiguous()
+        cosv, xn, yn, mx, mean, arg = K.pairwise_cosine_max_fwd(xd, yd, groups)
+        ctx.save_for_backward(xd, yd, cosv, xn, yn, arg)
+        ctx.mark_non_differentiable(mean, arg)
+        return mx, mean, arg
+
+    @staticmethod
+    def backward(ctx, dmax, _dmean, _darg):
+        x, y, cosv, xn, yn, arg = ctx.saved_tensors
+        dx, dy = K.pairwise_cosine_max_bwd(x, y, cosv, dmax, arg, xn, yn, need_dx=ctx.needs_input_grad[0])
+        return dx, (dy if ctx.needs_input_grad[1] else None), None
+
+
+def pairwise_cosine_max(x: torch.Tensor, y: torch.Tensor, groups: int = 1):
+    """MAX_EMB scoring (`Trainer.py:1691-1693`) for `groups` prompt sets at once: x [B,D], y [groups*Pg, D] ->
+    (max over each set's prompts [B,groups], their mean [B,groups] (logged only, not differentiable), winner index)."""
+    return _PairwiseCosineMax.apply(x, y, groups)
+
+
 class _GroupMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, groups, n):

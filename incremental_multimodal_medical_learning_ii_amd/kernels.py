@@ -171,11 +171,14 @@ def _kern(flops: float, exact: bool = False) -> str:
 
 def _label(la: str, lb: str, tile: str, M: int, N: int, K: int, splitk: int, kind: int, exact: bool = False,
            planes: bool = False) -> str:
-    """Profiler key of a launch: mainloop<A loader,B loader,tile>; planes operands take the 256x256 LDS-DMA kernel when the
-    library's policy picks it, else the split-bf16 mainloop on the 128x128-class tiles."""
+    """Profiler key of a launch: mainloop<A loader,B loader,tile>.  Planes operands take the LDS-DMA pipelined kernel — 256x256
+    tiles when the library's policy picks them, 128x128 (two blocks per CU) otherwise — except where one tile dimension is
+    <= 64, which stays on the register-staged split-bf16 mainloop (256x64 / 64x256 tiles)."""
     if planes:
         if _lib.load().cxrk_gemm_wide_tile(M, N, K, splitk, kind):
-            return f"gemm_pw_kernel<Dma{la},Dma{lb}>"
+            return f"gemm_pw_kernel<Pw256,Dma{la},Dma{lb}>"
+        if tile == "2,2":
+            return f"gemm_pw_kernel<Pw128,Dma{la},Dma{lb}>"
         return f"gemm_x3_kernel<{la}<PL>,{lb}<PL>,{tile}>"
     return f"{_kern(2.0 * M * N * K, exact)}<{la},{lb},{tile}>"
 
@@ -813,6 +816,51 @@ def pairwise_cosine_bwd(x, y, cosv, dcos, xn, yn, need_dx: bool = True):
                                        B, Pn, D, _p(dx), _p(dy), 0, _p(ws), ws.numel() * 4, _stream()),
           "cxrk_pairwise_cosine_bwd")
     return dx, dy
+
+
+def pairwise_cosine_max_fwd(x, y, groups: int):
+    """x [B,D], y [groups*Pg, D] -> cos [B,groups*Pg], max / mean over each group's prompts [B,groups], winner index (int32)."""
+    lib = _lib.load()
+    x = _chk(x, "cosine.x").contiguous()
+    y = _chk(y, "cosine.y").contiguous()
+    B, D = x.shape
+    Pn = y.shape[0]
+    if y.shape[1] != D or groups <= 0 or Pn % groups:
+        raise ValueError(f"pairwise_cosine_max: x is [{B},{D}], y is {tuple(y.shape)}, groups = {groups}")
+    f = dict(dtype=torch.float32, device=x.device)
+    cosv, xn, yn = torch.empty(B, Pn, **f), torch.empty(B, **f), torch.empty(Pn, **f)
+    mx, mean = torch.empty(B, groups, **f), torch.empty(B, groups, **f)
+    arg = torch.empty(B, groups, dtype=torch.int32, device=x.device)
+    check(lib.cxrk_pairwise_cosine_max_fwd(_p(x), _p(y), B, groups, Pn // groups, D, _p(cosv), _p(xn), _p(yn), _p(mx), _p(mean),
+                                           _p(arg), _stream()), "cxrk_pairwise_cosine_max_fwd")
+    return cosv, xn, yn, mx, mean, arg
+
+
+def pairwise_cosine_max_bwd(x, y, cosv, dmax, arg, xn, yn, need_dx: bool = True):
+    lib = _lib.load()
+    B, D = x.shape
+    Pn = y.shape[0]
+    G = arg.shape[1]
+    dx = torch.empty_like(x) if need_dx else None
+    dy = torch.empty_like(y)
+    ws = workspace(lib.cxrk_pairwise_cosine_bwd_ws_bytes(B, Pn, D), x.device)
+    check(lib.cxrk_pairwise_cosine_max_bwd(_p(x), _p(y), _p(cosv), _p(_chk(dmax.contiguous(), "cosine.dmax")), _p(arg), _p(xn), _p(yn),
+                                           B, G, Pn // G, D, _p(dx), _p(dy), 0, _p(ws), ws.numel() * 4, _stream()),
+          "cxrk_pairwise_cosine_max_bwd")
+    return dx, dy
+
+
+def patch_similarity(patches, text):
+    """patches [R,D] fp32, text [D] -> [R]: <patch_r, text> (vlp/inference_engine.py:104)."""
+    lib = _lib.load()
+    patches = _chk(patches, "patch_similarity.patches").contiguous()
+    text = _chk(text, "patch_similarity.text").contiguous().reshape(-1)
+    R, D = patches.shape
+    if text.numel() != D:
+        raise ValueError(f"patch_similarity: patches are [{R},{D}] but the text embedding has {text.numel()} features")
+    out = torch.empty(R, dtype=torch.float32, device=patches.device)
+    check(lib.cxrk_patch_similarity(_p(patches), _p(text), R, D, _p(out), _stream()), "cxrk_patch_similarity")
+    return out
 
 
 def bce_posneg_fwd_bwd(cosv, labels, diff: bool = True, need_grad: bool = True):

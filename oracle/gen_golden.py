@@ -236,10 +236,58 @@ def gen_g4_g5():
     print("G4/G5 written")
 
 
+def load_reference_vlp():
+    """`health_multimodal/vlp/inference_engine.py` by file path.  Its two package imports are only used in type annotations
+    (`ImageInferenceEngine`, `TextInferenceEngine`); the packages themselves import torchvision / transformers at module level
+    and cannot load here, so empty namespaces carrying those two names stand in for them."""
+    for pkg, name in (("health_multimodal", None), ("health_multimodal.image", "ImageInferenceEngine"),
+                      ("health_multimodal.text", "TextInferenceEngine"), ("health_multimodal.vlp", None)):
+        m = sys.modules.get(pkg)
+        if m is None:
+            m = types.ModuleType(pkg)
+            m.__path__ = []
+            sys.modules[pkg] = m
+        if name and not hasattr(m, name):
+            setattr(m, name, type(name, (), {}))
+    return _load_by_path("health_multimodal.vlp.inference_engine", os.path.join(REF, "health_multimodal", "vlp", "inference_engine.py"))
+
+
+def gen_g6():
+    """G6: patch-wise similarity map (`vlp/inference_engine.py:94-155`, expected values from the reference's own static
+    methods) and the MAX_EMB cosine head (`Trainer.py:1691-1693`; torchmetrics absent -> restatement only, parity unpinned)."""
+    rec = {}
+    vlp = load_reference_vlp().ImageTextInferenceEngine
+    pat = torch.nn.functional.normalize(torch.from_numpy(syn._normal("g6.patches", (15, 15, 128))), dim=-1)
+    txt = torch.nn.functional.normalize(torch.from_numpy(syn._normal("g6.text", (1, 128))), dim=-1)
+    sim = vlp._get_similarity_map_from_embeddings(pat, txt)
+    mine = ref_loss.similarity_map(pat, txt)
+    assert torch.equal(sim, mine), relerr(mine, sim)
+    rec["patches"], rec["text"], rec["sim"] = np_(pat), np_(txt), np_(sim)
+    cases = [(640, 512, 512, 480, "nearest"), (300, 420, 512, 480, "bilinear"), (97, 131, None, None, "nearest"),
+             (500, 500, None, 448, "bicubic")]
+    for i, (w, h, rs, cs, mode) in enumerate(cases):
+        exp = vlp.convert_similarity_to_image_size(sim, width=w, height=h, resize_size=rs, crop_size=cs, interpolation=mode)
+        got = ref_loss.similarity_to_image_size(sim, w, h, rs, cs, mode)
+        assert np.array_equal(exp, got, equal_nan=True)
+        rec[f"resize{i}_args"] = np.array([w, h, -1 if rs is None else rs, -1 if cs is None else cs])
+        rec[f"resize{i}_mode"] = np.array(mode)
+        rec[f"resize{i}_out"] = exp
+    x = torch.from_numpy(syn._normal("g6.x", (48, 128))).requires_grad_(True)
+    y = torch.from_numpy(syn._normal("g6.y", (10 * 4, 128))).requires_grad_(True)   # 5 classes x (pos, neg) x 4 prompts
+    y.data[5] = y.data[4]   # a tie inside one set: torch.max keeps the first
+    mx, mean, idx = ref_loss.pairwise_cosine_max(x, y, 10)
+    wgt = torch.from_numpy(syn._normal("g6.w", (48, 10)))
+    (mx * wgt).sum().backward()
+    rec.update(x=np_(x), y=np_(y), max=np_(mx), mean=np_(mean), argmax=np_(idx).astype(np.int32), dmax=np_(wgt), dx=np_(x.grad),
+               dy=np_(y.grad))
+    np.savez_compressed(os.path.join(OUT, "g6_simmap_maxemb.npz"), **rec)
+    print("G6 written")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g45"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6"]
     if "g1" in which:
         gen_g1()
     if "g2" in which:
@@ -248,3 +296,5 @@ if __name__ == "__main__":
         gen_g3()
     if "g45" in which:
         gen_g4_g5()
+    if "g6" in which:
+        gen_g6()

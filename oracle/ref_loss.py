@@ -18,6 +18,36 @@ def pairwise_cosine_similarity(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor
     return xn @ yn.T
 
 
+def pairwise_cosine_max(x: torch.Tensor, y: torch.Tensor, groups: int = 1):
+    """MAX_EMB branch of `Trainer.myCosineSimilarity` (`Trainer.py:1691-1693`) for `groups` prompt sets stacked in y
+    ([groups*Pg, D], set g = rows g*Pg..): cosines -> (max over the set, mean over the set, winner index), each [B, groups]."""
+    res = pairwise_cosine_similarity(x, y).reshape(x.shape[0], groups, -1)
+    mx, idx = torch.max(res, dim=2)
+    return mx, torch.mean(res, dim=2), idx
+
+
+def similarity_map(patches: torch.Tensor, text: torch.Tensor, sigma: float = 1.5) -> torch.Tensor:
+    """`vlp/inference_engine.py:94-108`: patches [h,w,D], text [1,D] -> scipy-gaussian-smoothed <patch, text> map [h,w]."""
+    from scipy import ndimage
+    h, w, d = patches.shape
+    raw = (patches.reshape(h * w, d) @ text.reshape(d, 1)).reshape(h, w).numpy()
+    return torch.from_numpy(ndimage.gaussian_filter(raw, sigma=(sigma, sigma), order=0))
+
+
+def similarity_to_image_size(sim: torch.Tensor, width: int, height: int, resize_size, crop_size, interpolation: str = "nearest"):
+    """`vlp/inference_engine.py:110-155` in numpy-free torch: stretch the patch grid over the crop's footprint in original
+    pixels (or the whole image when nothing was cropped), NaN outside."""
+    import math
+    g = sim[None, None]
+    ac = False if interpolation in ("linear", "bilinear", "bicubic", "trilinear") else None
+    if crop_size is None:
+        return F.interpolate(g, size=(height, width), mode=interpolation, align_corners=ac)[0, 0].numpy()
+    side = int(crop_size * min(height, width) / resize_size) if resize_size is not None else crop_size
+    m = F.interpolate(g, size=(side, side), mode=interpolation, align_corners=ac)[0, 0]
+    mw, mh = width - side, height - side
+    return F.pad(m, (math.floor(mw / 2), math.ceil(mw / 2), math.floor(mh / 2), math.ceil(mh / 2)), value=float("nan")).numpy()
+
+
 def posneg_logits(new_embs: torch.Tensor, pos: torch.Tensor, neg: torch.Tensor, diff: bool = True) -> torch.Tensor:
     """`Trainer.py:557-577`: logits[:, i] = cos(emb, pos_i) - cos(emb, neg_i) (or pos only).
     pos/neg: [C,128] prompt-mean vectors."""

@@ -2,6 +2,9 @@
 Tolerance: the north star's 1e-3 relative fp32 bar; the kernels are fp32 end to end so they are checked much
 tighter (2e-5 of the output scale) to catch layout / indexing mistakes."""
 import math
+import os
+
+import numpy as np
 
 import pytest
 import torch
@@ -10,6 +13,7 @@ import torch.nn.functional as F
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("precision")]
 
 from incremental_multimodal_medical_learning_ii_amd import kernels as K  # noqa: E402
+from incremental_multimodal_medical_learning_ii_amd import functional as Fh  # noqa: E402
 from oracle import ref_loss, ref_step  # noqa: E402
 
 DEV = "cuda"
@@ -456,6 +460,39 @@ def test_l2norm_infonce_pieces(golden_dir):
     lse, diag = K.infonce_row_lse(S.to(DEV), 0)
     close(lse, torch.logsumexp(S, 1), what="row lse")
     close(diag, S.diag(), what="diag")
+
+
+def test_pairwise_cosine_max_and_patch_similarity_vs_fixture(golden_dir):
+    """MAX_EMB head (`Trainer.py:1691-1693`) and the patch-wise similarity GEMV (`vlp/inference_engine.py:104`) against the
+    committed G6 vectors (similarity map: outputs of the reference's own static methods; cosine: restatement, parity unpinned)."""
+    g = np.load(os.path.join(golden_dir, "g6_simmap_maxemb.npz"))
+    x, y = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    cosv, xn, yn, mx, mean, arg = K.pairwise_cosine_max_fwd(x, y, 10)
+    close(mx, torch.from_numpy(g["max"]), what="max over prompts")
+    close(mean, torch.from_numpy(g["mean"]), what="mean over prompts")
+    assert torch.equal(arg.cpu(), torch.from_numpy(g["argmax"])), "winner index (first on ties)"
+    assert int(arg[0, 1]) in (0, 1, 2, 3) and not bool((arg[:, 1] == 1).any()), "rows 4 and 5 of y are equal: index 0 must win over 1"
+    dx, dy = K.pairwise_cosine_max_bwd(x, y, cosv, torch.from_numpy(g["dmax"]).to(DEV), arg, xn, yn)
+    close(dx, torch.from_numpy(g["dx"]), what="max-cosine dx")
+    close(dy, torch.from_numpy(g["dy"]), what="max-cosine dy")
+    # autograd surface + ragged sizes (B not a multiple of the 4 rows per block, one prompt per group = plain cosine)
+    xs, ys = rnd(7, 128, seed=3).to(DEV).requires_grad_(True), rnd(3, 128, seed=4).to(DEV).requires_grad_(True)
+    m1, a1, _ = Fh.pairwise_cosine_max(xs, ys, 3)
+    close(m1, ref_loss.pairwise_cosine_similarity(xs.detach().cpu(), ys.detach().cpu()), what="Pg = 1 is the plain cosine")
+    close(a1, m1.detach(), what="mean of one")
+    m1.sum().backward()
+    xr, yr = xs.detach().cpu().requires_grad_(True), ys.detach().cpu().requires_grad_(True)
+    ref_loss.pairwise_cosine_max(xr, yr, 3)[0].sum().backward()
+    close(xs.grad, xr.grad, what="dx via autograd"); close(ys.grad, yr.grad, what="dy via autograd")
+    # similarity map: HIP GEMV + host gaussian == the reference's _get_similarity_map_from_embeddings output, then its resize
+    from incremental_multimodal_medical_learning_ii_amd.health_multimodal.vlp import ImageTextInferenceEngine as E
+    pat, txt = torch.from_numpy(g["patches"]).to(DEV), torch.from_numpy(g["text"]).to(DEV)
+    raw = K.patch_similarity(pat.reshape(-1, 128), txt[0])
+    close(raw, (torch.from_numpy(g["patches"]).reshape(-1, 128) @ torch.from_numpy(g["text"]).T).reshape(-1), what="patch . text")
+    sim = E._get_similarity_map_from_embeddings(pat, txt)
+    assert sim.shape == (15, 15) and float((sim - torch.from_numpy(g["sim"])).abs().max()) < 1e-6
+    with pytest.raises(ValueError):
+        K.patch_similarity(pat.reshape(-1, 128), txt[0, :64])
 
 
 def test_pairwise_cosine_bce_eval(golden_dir):

@@ -105,3 +105,76 @@ def test_optimizer_fixed_points_on_flat_buffers():
     ropt.step()
     assert rel(p[0].detach().cpu(), ref[0].detach()) < 1e-6
     assert torch.equal(p[1].detach(), before[1])
+
+
+def _cfg2_trainer():
+    from incremental_multimodal_medical_learning_ii_amd.contrastive import JointContrastiveTrainer
+    from incremental_multimodal_medical_learning_ii_amd.health_multimodal.image.model import get_biovil_resnet
+    im = get_biovil_resnet(None).eval()
+    tm = CXRBertModel(CXRBertConfig()).eval()
+    syn.fill_module_(im)
+    syn.fill_module_(tm)
+    return JointContrastiveTrainer(im.to(DEV), tm.to(DEV), lr=1e-4, temperature=0.07)
+
+
+def test_cfg2_joint_step_batch_256_full_models():
+    """BASELINE config 2 (`Trainer.py` joint training shape at batch 256) on the full ResNet-50 (224 px) + 12-layer CXR-BERT, where
+    the CPU oracle would take minutes: the split-bf16 product path against the exact-fp32 path of the same kernels (embeddings,
+    loss and one gradient tensor of each encoder within the north star's 1e-3), run-to-run bit equality, and a loss that falls."""
+    from incremental_multimodal_medical_learning_ii_amd import _lib
+    B = 256
+    images = syn.synthetic_images(B, 224, seed=31).to(DEV)
+    ids, mask = syn.synthetic_tokens(B, 32, seed=32)
+    ids, mask = ids.to(DEV), mask.to(DEV)
+    tr = _cfg2_trainer()
+    inamed, tnamed = dict(tr.image_model.named_parameters()), dict(tr.text_model.named_parameters())
+    probes = [inamed["encoder.encoder.layer3.2.conv2.weight"], tnamed["bert.encoder.layer.5.attention.output.dense.weight"],
+              inamed["projector.model.0.weight"]]
+    old = _lib.get_precision()
+    out = {}
+    try:
+        for mode in ("fp32", "split_bf16", "split_bf16"):
+            _lib.set_precision(mode)
+            tr.optimizer.zero_grad()
+            loss = tr.forward_loss(images, ids, mask)
+            loss.backward()
+            with torch.no_grad():
+                ie = tr.image_model(images[:32]).clone()
+            rec = (float(loss), ie, [p.grad.detach().clone() for p in probes])
+            if mode in out:   # second split-bf16 run: same bits (no atomics, fixed reduction order)
+                assert rec[0] == out[mode][0] and torch.equal(rec[1], out[mode][1])
+                assert all(torch.equal(a, b) for a, b in zip(rec[2], out[mode][2]))
+            out[mode] = rec
+        a, b = out["fp32"], out["split_bf16"]
+        assert math.isfinite(b[0]) and abs(b[0] - a[0]) / abs(a[0]) < 1e-3
+        assert rel(b[1], a[1]) < 1e-3
+        for ga, gb in zip(a[2], b[2]):
+            assert float((gb - ga).norm() / ga.norm()) < 1e-3
+        _lib.set_precision("split_bf16")
+        l0 = float(tr.step(images, ids, mask))
+        for _ in range(3):
+            l1 = float(tr.step(images, ids, mask))
+        assert math.isfinite(l1) and l1 < l0 and abs(l0 - b[0]) < 1e-6
+    finally:
+        _lib.set_precision(old)
+
+
+def test_embedding_precompute_at_reference_image_size():
+    """`chexpert-get-embedding.py:48-74` operating point: frozen encoder, 512 x 512 images, a large batch.  Checks the batch
+    pipeline against the same images encoded one at a time (the reference's batch size 1) and the chunk files it writes."""
+    import tempfile
+    from incremental_multimodal_medical_learning_ii_amd.embedding_precompute import compute_embeddings, synthetic_image_batches
+    from incremental_multimodal_medical_learning_ii_amd.health_multimodal.image.model import get_biovil_resnet
+    im = get_biovil_resnet(None).eval()
+    syn.fill_module_(im)
+    im = im.to(DEV)
+    with tempfile.TemporaryDirectory() as d:
+        embs, labels = compute_embeddings(im, synthetic_image_batches(80, 64, size=512), out_dir=d, checkpoint_interval=64)
+        assert embs.shape == (80, 128) and labels.shape == (80, 5) and bool(torch.isfinite(embs).all())
+        first = torch.load(d + "/embeddings_dataset_64.pt", weights_only=True)
+        final = torch.load(d + "/embeddings_dataset_final_old.pt", weights_only=True)
+        assert torch.equal(first["embs"], embs[:64]) and torch.equal(final["embs"], embs) and torch.equal(final["labels"], labels)
+    one, _ = next(iter(synthetic_image_batches(80, 64, size=512)))
+    with torch.no_grad():
+        single = torch.cat([im(one[i:i + 1].to(DEV)) for i in (0, 17, 63)]).cpu()
+    assert rel(embs[[0, 17, 63]], single) < 1e-4   # batch independence of the eval-mode encoder at 512 px
