@@ -174,6 +174,7 @@ int cxrk_gelu_bwd(const float* dy, const float* pre, long n, float* dx, hipStrea
 /* ------------------------------------------------------------------------------------------------------------
  * Similarity / loss heads.
  * l2norm:      F.normalize(x, dim=1) (modelling_cxrbert.py:138-139; vlp/inference_engine.py:51): xhat = x / max(|x|, eps).
+ *              xhat rows are ldxhat floats apart (the data-parallel step writes image and text halves of one [B][2D] send buffer).
  * infonce:     north-star head (not in the reference): on a logits block S[rows][cols] = X_hat_local @ Y_hat_all^T / tau,
  *              row_lse gives lse + diagonal (+ accumulates sum(lse-diag)*scale into loss_out);
  *              grad_inplace turns S into exp(S-lse_row[i]) + exp(S-lse_col[j]) - 2*[j==diag_off+i].
@@ -189,8 +190,8 @@ int cxrk_gelu_bwd(const float* dy, const float* pre, long n, float* dx, hipStrea
  * eval_score:  Trainer.val/test scoring (Trainer.py:825-836).
  * group_mean:  prompt-embedding mean over the prompts of a class (Trainer.py:1665-1666).
  */
-int cxrk_l2norm_fwd(const float* x, long rows, int D, float eps, float* xhat, float* norm, hipStream_t stream);
-int cxrk_l2norm_bwd(const float* dxhat, const float* xhat, const float* norm, long rows, int D, float* dx,
+int cxrk_l2norm_fwd(const float* x, long rows, int D, float eps, float* xhat, long ldxhat, float* norm, hipStream_t stream);
+int cxrk_l2norm_bwd(const float* dxhat, const float* xhat, long ldxhat, const float* norm, long rows, int D, float* dx,
                     hipStream_t stream);
 int cxrk_infonce_row_lse(const float* S, long ld, int rows, int cols, int diag_off, float* lse, float* diag,
                          float* loss_out, float loss_scale, int loss_accumulate, hipStream_t stream);

@@ -53,8 +53,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_attn_bwd": (I, [P, P, P, I, I, I, I, P, L, P]),
     "cxrk_embed_bwd": (I, [P, P, L, I, P, P]),
     "cxrk_gelu_bwd": (I, [P, P, L, P, P]),
-    "cxrk_l2norm_fwd": (I, [P, L, I, F, P, P, P]),
-    "cxrk_l2norm_bwd": (I, [P, P, P, L, I, P, P]),
+    "cxrk_l2norm_fwd": (I, [P, L, I, F, P, L, P, P]),
+    "cxrk_l2norm_bwd": (I, [P, P, L, P, L, I, P, P]),
     "cxrk_infonce_row_lse": (I, [P, L, I, I, I, P, P, P, F, I, P]),
     "cxrk_infonce_grad_inplace": (I, [P, L, I, I, I, P, P, P]),
     "cxrk_pairwise_cosine_fwd": (I, [P, P, L, I, I, P, P, P, P]),

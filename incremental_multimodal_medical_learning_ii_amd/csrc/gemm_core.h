@@ -469,13 +469,14 @@ int wgrad_splitk_policy(int M, int N, int K, bool planes);   // gemm.hip
 inline int& wide_mode_ref() { static int m = [] { const char* e = getenv("CXRK_WIDE"); return e ? atoi(e) : 1; }(); return m; }
 inline int wide_mode() { return wide_mode_ref(); }
 // min_k: shortest K loop (per split-K slab) for which the caller's kind of launch gains (measured per kind on the step's
-// shapes, scripts/layer_table.py: the heavier the fused epilogue, the longer the loop has to be to pay for exposing it).
+// shapes, scripts/layer_table.py under CXRK_MINK_* overrides; r2k: data gradients gain on the 256x256 tile at every K — their
+// N = C_in >= 256 outputs dominate and the larger tile halves the dy / filter re-reads — forward convolutions only from K = 512).
 static inline long env_long(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
 #define WIDE_MINK_PLAIN (wide_mink(0))   // dense layers, weight gradients
 #define WIDE_MINK_FPROP (wide_mink(1))   // convolution forward (shift + residual + ReLU)
 #define WIDE_MINK_DGRAD (wide_mink(2))   // convolution data gradient (ReLU mask + fused BatchNorm sums)
 inline long wide_mink(int kind) {
-  static const long v[3] = {env_long("CXRK_MINK_PLAIN", 512), env_long("CXRK_MINK_FPROP", 512), env_long("CXRK_MINK_DGRAD", 1024)};
+  static const long v[3] = {env_long("CXRK_MINK_PLAIN", 512), env_long("CXRK_MINK_FPROP", 512), env_long("CXRK_MINK_DGRAD", 64)};
   return v[kind];
 }
 static inline bool use_wide256(int M, int N, long K, int splitk, bool planes, long min_k = WIDE_MINK_PLAIN) {

@@ -16,7 +16,7 @@ namespace {
 constexpr int NV = 8;
 
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, long rows, int D, float eps,
-                                                         float* __restrict__ xhat, float* __restrict__ norm) {
+                                                         float* __restrict__ xhat, long ldh, float* __restrict__ norm) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -26,12 +26,12 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict
   const float n = sqrtf(wave_sum(q));
   const float inv = 1.0f / fmaxf(n, eps);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) { const int c = lane + i * 64; if (c < D) xhat[row * D + c] = v[i] * inv; }
+  for (int i = 0; i < NV; ++i) { const int c = lane + i * 64; if (c < D) xhat[row * ldh + c] = v[i] * inv; }
   if (lane == 0 && norm) norm[row] = fmaxf(n, eps);
 }
 
 // dx = (dxhat - xhat * <xhat, dxhat>) / norm
-__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dxhat, const float* __restrict__ xhat,
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dxhat, const float* __restrict__ xhat, long ldh,
                                                          const float* __restrict__ norm, long rows, int D,
                                                          float* __restrict__ dx) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
-    g[i] = c < D ? dxhat[row * D + c] : 0.f; h[i] = c < D ? xhat[row * D + c] : 0.f; dot += g[i] * h[i];
+    g[i] = c < D ? dxhat[row * D + c] : 0.f; h[i] = c < D ? xhat[row * ldh + c] : 0.f; dot += g[i] * h[i];
   }
   dot = wave_sum(dot);
   const float inv = 1.0f / norm[row];
@@ -271,16 +271,16 @@ extern "C" int cxrk_scale_mask(const float* x, const float* mask_src, const floa
   return CXRK_OK;
 }
 
-extern "C" int cxrk_l2norm_fwd(const float* x, long rows, int D, float eps, float* xhat, float* norm, hipStream_t stream) {
-  CXRK_CHECK_ARG(x && xhat && rows > 0 && D > 0 && D <= 64 * NV);
-  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, rows, D, eps, xhat, norm);
+extern "C" int cxrk_l2norm_fwd(const float* x, long rows, int D, float eps, float* xhat, long ldxhat, float* norm, hipStream_t stream) {
+  CXRK_CHECK_ARG(x && xhat && rows > 0 && D > 0 && D <= 64 * NV && ldxhat >= D);
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, rows, D, eps, xhat, ldxhat, norm);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
 }
-extern "C" int cxrk_l2norm_bwd(const float* dxhat, const float* xhat, const float* norm, long rows, int D, float* dx,
+extern "C" int cxrk_l2norm_bwd(const float* dxhat, const float* xhat, long ldxhat, const float* norm, long rows, int D, float* dx,
                                hipStream_t stream) {
-  CXRK_CHECK_ARG(dxhat && xhat && norm && dx && rows > 0 && D > 0 && D <= 64 * NV);
-  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, dxhat, xhat, norm, rows, D, dx);
+  CXRK_CHECK_ARG(dxhat && xhat && norm && dx && rows > 0 && D > 0 && D <= 64 * NV && ldxhat >= D);
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, dxhat, xhat, ldxhat, norm, rows, D, dx);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
 }

@@ -183,17 +183,19 @@ def posneg_bce_loss(cosv: torch.Tensor, labels: torch.Tensor, diff: bool = True)
 # InfoNCE (north star; SURVEY.md a13 / §8e)
 # --------------------------------------------------------------------------------------------------------------
 
-def _all_gather_cat(t: torch.Tensor, group) -> torch.Tensor:
+def _all_gather_rows(t: torch.Tensor, group) -> torch.Tensor:
+    """[rows, ...] contiguous on every rank -> [world * rows, ...], rank-major.  One collective, no staging copy on RCCL."""
     import torch.distributed as dist
     ws = dist.get_world_size(group)
+    assert t.is_contiguous()
     out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     if t.is_cuda and dist.get_backend(group) == "gloo":
         # gloo has no GPU all-gather: stage through the host (rehearsals of the N>1 path on one GPU; RCCL takes the line below)
         host = torch.empty(out.shape, dtype=t.dtype)
-        dist.all_gather_into_tensor(host, t.detach().cpu().contiguous(), group=group)
+        dist.all_gather_into_tensor(host, t.detach().cpu(), group=group)
         out.copy_(host)
         return out
-    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    dist.all_gather_into_tensor(out, t, group=group)
     return out
 
 
@@ -220,14 +222,19 @@ class _InfoNCE(torch.autograd.Function):
             # is issued, not inside loss.backward() with the other ranks already waiting in the gradient all-reduce
             raise ValueError(f"infonce_loss: global batch {B * world_} (= {B} rows x {world_} ranks) and embedding size {D} must be "
                              f"multiples of 4 (drop or pad the ragged last batch)")
-        ih, inorm = K.l2norm_fwd(img)
-        th, tnorm = K.l2norm_fwd(txt)
         if dist_on:
+            # image and text halves of ONE [B, 2D] send buffer, written in place by the normalisation kernels; the gathered
+            # [Bg, 2D] buffer is read by the GEMMs through its column halves (row stride 2D): no cat / contiguous copies
             rank, world = dist.get_rank(group), dist.get_world_size(group)
-            both = _all_gather_cat(torch.cat([ih, th], dim=1), group)      # [Bg, 2D]
-            ih_all, th_all = both[:, :D].contiguous(), both[:, D:].contiguous()
+            send = torch.empty(B, 2 * D, dtype=torch.float32, device=img.device)
+            ih, inorm = K.l2norm_fwd(img, out=send[:, :D])
+            th, tnorm = K.l2norm_fwd(txt, out=send[:, D:])
+            both = _all_gather_rows(send, group)                           # [Bg, 2D]
+            ih_all, th_all = both[:, :D], both[:, D:]
         else:
             rank, world = 0, 1
+            ih, inorm = K.l2norm_fwd(img)
+            th, tnorm = K.l2norm_fwd(txt)
             ih_all, th_all = ih, th
         Bg = B * world
         off = rank * B
@@ -241,8 +248,7 @@ class _InfoNCE(torch.autograd.Function):
         lse2, _ = K.infonce_row_lse(S2, off, loss_out=loss, loss_scale=0.5 / Bg, loss_accumulate=True)
         if dist_on:
             dist.all_reduce(loss, group=group)
-            lse_all = _all_gather_cat(torch.stack([lse1, lse2], dim=1), group)  # [Bg, 2]
-            lse1_all, lse2_all = lse_all[:, 0].contiguous(), lse_all[:, 1].contiguous()
+            lse1_all, lse2_all = _all_gather_rows(lse1, group), _all_gather_rows(lse2, group)   # [Bg] each (4 KiB per rank)
         else:
             lse1_all, lse2_all = lse1, lse2
         ctx.save_for_backward(S1, S2, lse1, lse2, lse1_all, lse2_all, ih, th, ih_all, th_all, inorm, tnorm)

@@ -22,8 +22,8 @@ Two storage modes, chosen by the library's contraction precision (`_lib.get_prec
   split_bf16  every activation / gradient / folded filter that feeds a contraction is a `kernels.Planes` tensor (bf16 hi + lo
               planes, 4 bytes per element) written by the producing kernel's epilogue, so the MFMA mainloops load operands with
               no conversion work; ReLU decisions are saved as bit masks (1 bit per element) by the forward epilogues and read
-              by the data-gradient epilogues.  The stem reads the fp32 image (fp32 gather, split on the fly) and its weight
-              gradient stays exact fp32 (an all-positive input makes it a cancelling sum).
+              by the data-gradient epilogues.  The stem reads the fp32 image (fp32 gather, split on the fly), in the forward
+              and in its weight gradient.
 Parameter gradients are written (accumulated) straight into `param.grad` when that exists with the parameter's own memory
 layout — the flat gradient buffer of `optim._FlatOptimizer` — so autograd has nothing to add afterwards.
 """
@@ -327,7 +327,7 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
     if _debug is not None:
         _debug["ds"], _debug["x0"] = ds, x0
     sum_s = K.colsum(ds.view(-1, ds.shape[-1]), torch.empty(ds.shape[-1], dtype=torch.float32, device=dev))
-    _unit_params_bwd(0, specs[0], fold, p, bufs, x0, ds, sum_s, N, H, W, sink, False)   # exact fp32 in both modes
+    _unit_params_bwd(0, specs[0], fold, p, bufs, x0, ds, sum_s, N, H, W, sink, False)   # fp32 operands (the image), split on the fly in split_bf16 mode
     return sink.ret
 
 

@@ -469,7 +469,7 @@ def conv_bwd_params(x, dy, w, scale, rstd, rmean, sumdy, dw, dgamma, dbeta, accu
         fl = 2.0 * N * Ho * Wo * Ko * R * S * Cpad
         sk = lib.cxrk_gemm_wgrad_splitk(Ko, R * S * Cpad, N * Ho * Wo, 0)
         ev = profiler.bracket(_label("DenseMC", "ConvIm2colMC", "1,4" if Ko <= 64 else "2,2", Ko, R * S * Cpad, N * Ho * Wo, sk, 0,
-                                     Cpad <= 4), fl, 4.0 * (N * H * W * Cpad + N * Ho * Wo * Ko + Ko * R * S * Cpad))
+                                     False), fl, 4.0 * (N * H * W * Cpad + N * Ho * Wo * Ko + Ko * R * S * Cpad))
     check(lib.cxrk_conv_bn_act_bwd_params(_p(_chk(x, "conv.x")), _p(_chk(dy, "conv.dy")), _p(w), _p(scale), _p(rstd),
                                           _p(rmean), _p(sumdy), _p(dw), _p(dgamma), _p(dbeta), int(accumulate), N, H, W,
                                           C, Cpad, Ko, R, S, stride, pad, _p(ws), ws.numel() * 4, _stream()),
@@ -750,21 +750,26 @@ def gelu_bwd(dy, pre):
 # heads
 # ----------------------------------------------------------------------------------------------------------------
 
-def l2norm_fwd(x: torch.Tensor, eps: float = 1e-12):
+def l2norm_fwd(x: torch.Tensor, eps: float = 1e-12, out: Optional[torch.Tensor] = None):
+    """xhat = x / max(|x|, eps) row-wise; `out` may be a column slice of a wider buffer (rows out.stride(0) apart)."""
     lib = _lib.load()
     x = _chk(x, "l2norm.x").contiguous()
     rows, D = x.shape
-    xhat = torch.empty_like(x)
+    xhat = torch.empty_like(x) if out is None else _chk(out, "l2norm.out")
+    if tuple(xhat.shape) != (rows, D) or xhat.stride(1) != 1:
+        raise ValueError(f"l2norm.out must be [{rows},{D}] with contiguous columns, got {tuple(xhat.shape)} strides {xhat.stride()}")
     norm = torch.empty(rows, dtype=torch.float32, device=x.device)
-    check(lib.cxrk_l2norm_fwd(_p(x), rows, D, float(eps), _p(xhat), _p(norm), _stream()), "cxrk_l2norm_fwd")
+    check(lib.cxrk_l2norm_fwd(_p(x), rows, D, float(eps), _p(xhat), xhat.stride(0), _p(norm), _stream()), "cxrk_l2norm_fwd")
     return xhat, norm
 
 
 def l2norm_bwd(dxhat, xhat, norm):
     lib = _lib.load()
     rows, D = xhat.shape
-    dx = torch.empty_like(xhat)
-    check(lib.cxrk_l2norm_bwd(_p(_chk(dxhat.contiguous(), "l2norm.dxhat")), _p(xhat), _p(norm), rows, D, _p(dx),
+    if xhat.stride(1) != 1:
+        raise ValueError("l2norm_bwd: xhat columns must be contiguous")
+    dx = torch.empty(rows, D, dtype=torch.float32, device=xhat.device)
+    check(lib.cxrk_l2norm_bwd(_p(_chk(dxhat.contiguous(), "l2norm.dxhat")), _p(xhat), xhat.stride(0), _p(norm), rows, D, _p(dx),
                               _stream()), "cxrk_l2norm_bwd")
     return dx
 

@@ -4,9 +4,12 @@ with the gloo backend on CPU, where no HIP kernel can run.  It is never imported
 import torch
 
 
-def l2norm_fwd(x, eps=1e-12):
+def l2norm_fwd(x, eps=1e-12, out=None):
     n = x.norm(dim=1).clamp_min(eps)
-    return x / n[:, None], n
+    if out is None:
+        return x / n[:, None], n
+    out.copy_(x / n[:, None])
+    return out, n
 
 
 def l2norm_bwd(dxhat, xhat, norm):
