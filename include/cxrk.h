@@ -158,9 +158,11 @@ int cxrk_embed_ln_fwd(const long* ids, const float* word, const float* pos, cons
 int cxrk_residual_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float eps, long rows,
                          int H, void* y, long yplane, float* xhat, float* rstd, hipStream_t stream);
 size_t cxrk_residual_ln_bwd_ws_bytes(long rows, int H);
+/* dxsum (optional, [H]): column sums of the gradient this call writes (dx, dx_add included) = the bias gradient of the dense layer
+ * whose output fed this LayerNorm (BertSelfOutput / BertOutput dense), reduced in the same pass. */
 int cxrk_residual_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, long rows, int H,
-                         const float* dx_add, void* dx, long dxplane, float* dgamma, float* dbeta, int accumulate, float* ws,
-                         size_t ws_bytes, hipStream_t stream);
+                         const float* dx_add, void* dx, long dxplane, float* dgamma, float* dbeta, int accumulate, float* dxsum,
+                         int dxsum_accumulate, float* ws, size_t ws_bytes, hipStream_t stream);
 /* dst[r*ld + c] += src[r][c] for a planes tensor src [rows][cols] (the CLS-row gradient added into a [N, L, H] fp32 gradient) */
 int cxrk_planes_add_rows(const void* src, long plane, long rows, int cols, float* dst, long ld, hipStream_t stream);
 int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, int nH, int dH, void* ctx, long ctxplane, float* probs,

@@ -47,7 +47,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_embed_ln_fwd": (I, [P, P, P, P, P, P, F, L, I, I, P, L, P, P, P]),
     "cxrk_residual_ln_fwd": (I, [P, P, P, P, F, L, I, P, L, P, P, P]),
     "cxrk_residual_ln_bwd_ws_bytes": (Z, [L, I]),
-    "cxrk_residual_ln_bwd": (I, [P, P, P, P, L, I, P, P, L, P, P, I, P, Z, P]),
+    "cxrk_residual_ln_bwd": (I, [P, P, P, P, L, I, P, P, L, P, P, I, P, I, P, Z, P]),
     "cxrk_planes_add_rows": (I, [P, L, L, I, P, L, P]),
     "cxrk_attn_fwd": (I, [P, P, I, I, I, I, P, L, P, P]),
     "cxrk_attn_bwd": (I, [P, P, P, I, I, I, I, P, L, P]),

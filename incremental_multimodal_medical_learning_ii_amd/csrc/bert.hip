@@ -182,17 +182,19 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* __restrict
                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                          long rows, int H, int rows_per, float* __restrict__ dx,
                                                          unsigned short* __restrict__ dxp, long dxplane,
-                                                         const float* __restrict__ dx_add, float* __restrict__ part) {
-  __shared__ float sh[2][4][64 * LN_MAXV];
+                                                         const float* __restrict__ dx_add, float* __restrict__ part, int np) {
+  // np = 2: partials of dgamma, dbeta; np = 3: also the column sums of the OUTPUT (the bias gradient of the dense layer that
+  // produced this LayerNorm's input: its dy is exactly what this kernel writes, so the separate column-sum pass over it goes away)
+  __shared__ float sh[3][4][64 * LN_MAXV];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long r0 = (long)blockIdx.x * rows_per;
   const long r1 = min(rows, r0 + rows_per);
   const int H4 = H / 4;
-  float4 dg[LN_MAXV4], db[LN_MAXV4], gm[LN_MAXV4];
+  float4 dg[LN_MAXV4], db[LN_MAXV4], gm[LN_MAXV4], ds[LN_MAXV4];
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < LN_MAXV4; ++i) {
-    dg[i] = z4; db[i] = z4;
+    dg[i] = z4; db[i] = z4; ds[i] = z4;
     const int c4 = lane + i * 64;
     gm[i] = c4 < H4 ? *reinterpret_cast<const float4*>(gamma + c4 * 4) : z4;
   }
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* __restrict
         float4 o = make_float4(rs * (g[i].x - s1 - xh[i].x * s2), rs * (g[i].y - s1 - xh[i].y * s2),
                                rs * (g[i].z - s1 - xh[i].z * s2), rs * (g[i].w - s1 - xh[i].w * s2));
         if (dx_add) { const float4 a = *reinterpret_cast<const float4*>(dx_add + row * H + c4 * 4); o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+        ds[i].x += o.x; ds[i].y += o.y; ds[i].z += o.z; ds[i].w += o.w;
         if (dxp) { const float ov[4] = {o.x, o.y, o.z, o.w}; planes_store4(dxp, dxplane, row * H + c4 * 4, ov); }
         else *reinterpret_cast<float4*>(dx + row * H + c4 * 4) = o;
       }
@@ -231,31 +234,31 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* __restrict
     if (c < 64 * LN_MAXV) {
       *reinterpret_cast<float4*>(&sh[0][w][c]) = dg[i];
       *reinterpret_cast<float4*>(&sh[1][w][c]) = db[i];
+      *reinterpret_cast<float4*>(&sh[2][w][c]) = ds[i];
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < H; c += 256) {
-    part[((long)blockIdx.x * 2 + 0) * H + c] = (sh[0][0][c] + sh[0][1][c]) + (sh[0][2][c] + sh[0][3][c]);
-    part[((long)blockIdx.x * 2 + 1) * H + c] = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
-  }
+  for (int c = threadIdx.x; c < H; c += 256)
+    for (int k = 0; k < np; ++k) part[((long)blockIdx.x * np + k) * H + c] = (sh[k][0][c] + sh[k][1][c]) + (sh[k][2][c] + sh[k][3][c]);
 }
 // Column sums of the block partials: 64 columns x 16 partial groups per block, groups added in order through LDS.
-__global__ __launch_bounds__(1024) void ln_bwd_final_kernel(const float* __restrict__ part, int nblk, int H, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int accumulate) {
+__global__ __launch_bounds__(1024) void ln_bwd_final_kernel(const float* __restrict__ part, int nblk, int np, int H, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int accumulate, float* __restrict__ dxsum,
+                                                            int dxsum_accumulate) {
   __shared__ float sh[16][64];
   const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl, k = blockIdx.y;
   float a = 0.f;
   if (c < H)
-    for (int p = pl; p < nblk; p += 16) a += part[((long)p * 2 + k) * H + c];
+    for (int p = pl; p < nblk; p += 16) a += part[((long)p * np + k) * H + c];
   sh[pl][cl] = a;
   __syncthreads();
   if (pl == 0 && c < H) {
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += sh[i][cl];
-    float* out = k == 0 ? dgamma : dbeta;
-    out[c] = accumulate ? out[c] + t : t;
+    float* out = k == 0 ? dgamma : (k == 1 ? dbeta : dxsum);
+    out[c] = (k == 2 ? dxsum_accumulate : accumulate) ? out[c] + t : t;
   }
 }
 
@@ -527,27 +530,29 @@ static int ln_bwd_blocks(long rows) {
   if (nb < 1) nb = 1;
   return (int)nb;
 }
-extern "C" size_t cxrk_residual_ln_bwd_ws_bytes(long rows, int H) { return (size_t)ln_bwd_blocks(rows) * 2 * H * sizeof(float); }
+extern "C" size_t cxrk_residual_ln_bwd_ws_bytes(long rows, int H) { return (size_t)ln_bwd_blocks(rows) * 3 * H * sizeof(float); }
 
 extern "C" int cxrk_residual_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, long rows,
                                     int H, const float* dx_add, void* dxv, long dxplane, float* dgamma, float* dbeta, int accumulate,
-                                    float* ws, size_t ws_bytes, hipStream_t stream) {
+                                    float* dxsum, int dxsum_accumulate, float* ws, size_t ws_bytes, hipStream_t stream) {
   CXRK_CHECK_ARG(dy && xhat && rstd && gamma && dxv && dgamma && dbeta && rows > 0 && H > 0 && H <= 64 * LN_MAXV && dxplane >= 0);
   float* dx = dxplane ? nullptr : static_cast<float*>(dxv);
   unsigned short* dxp = dxplane ? static_cast<unsigned short*>(dxv) : nullptr;
   int nb = ln_bwd_blocks(rows);
-  if (ws == nullptr || ws_bytes < (size_t)nb * 2 * H * sizeof(float)) return CXRK_ERR_WS;
+  if (ws == nullptr || ws_bytes < (size_t)nb * 3 * H * sizeof(float)) return CXRK_ERR_WS;
+  const int np = dxsum ? 3 : 2;
   const int rows_per = (int)((rows + nb - 1) / nb);
   nb = (int)((rows + rows_per - 1) / rows_per);
   const bool vec = (H % 4 == 0) && aligned16(dy) && aligned16(xhat) && aligned16(gamma) && aligned16(dxv) && (!dx_add || aligned16(dx_add)) &&
                    (dxplane % 4) == 0;
-  if (dxp && !vec) return CXRK_ERR_ARG;
+  if ((dxp || dxsum) && !vec) return CXRK_ERR_ARG;
   if (vec)
-    hipLaunchKernelGGL(ln_bwd_vec_kernel, dim3(nb), dim3(256), 0, stream, dy, xhat, rstd, gamma, rows, H, rows_per, dx, dxp, dxplane, dx_add, ws);
+    hipLaunchKernelGGL(ln_bwd_vec_kernel, dim3(nb), dim3(256), 0, stream, dy, xhat, rstd, gamma, rows, H, rows_per, dx, dxp, dxplane, dx_add, ws, np);
   else
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, stream, dy, xhat, rstd, gamma, rows, H, rows_per, dx, dx_add, ws);
   CXRK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(ceil_div(H, 64), 2), dim3(1024), 0, stream, ws, nb, H, dgamma, dbeta, accumulate);
+  hipLaunchKernelGGL(ln_bwd_final_kernel, dim3(ceil_div(H, 64), np), dim3(1024), 0, stream, ws, nb, np, H, dgamma, dbeta, accumulate, dxsum,
+                     dxsum_accumulate);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
 }

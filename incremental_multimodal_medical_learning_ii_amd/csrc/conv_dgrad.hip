@@ -73,8 +73,13 @@ static int conv_bwd_data_impl(const typename FMT::T* dy, long dyplane, const typ
         rc = launch_gemm_pw<Pw256, DmaConvDgradKC<256, 8>, DmaConvFilterMC<256, 8>>(pa, pb, ep, M, C, K, 1, stream);
       } else return CXRK_ERR_UNSUPPORTED;
     } else if (C <= 64) {
-      typename ConvDgradKC<256, FMT>::P pa{dy, g, M, K, dyplane}; typename ConvFilterMC<64, FMT>::P pb{w, g, C, K, wplane};
-      rc = launch_gemm<ConvDgradKC<256, FMT>, ConvFilterMC<64, FMT>, 4, 1>(pa, pb, ep, M, C, K, 1, stream);
+      if constexpr (FMT::PLANES) {
+        DmaConvDgradKC<256, 4>::P pa{dy, g, M, K, dyplane}; DmaConvFilterMC<64, 4>::P pb{w, g, C, K, wplane};
+        rc = launch_gemm_pw<Pw256x64, DmaConvDgradKC<256, 4>, DmaConvFilterMC<64, 4>>(pa, pb, ep, M, C, K, 1, stream);
+      } else {
+        typename ConvDgradKC<256, FMT>::P pa{dy, g, M, K, dyplane}; typename ConvFilterMC<64, FMT>::P pb{w, g, C, K, wplane};
+        rc = launch_gemm<ConvDgradKC<256, FMT>, ConvFilterMC<64, FMT>, 4, 1>(pa, pb, ep, M, C, K, 1, stream);
+      }
     } else if constexpr (FMT::PLANES) {
       DmaConvDgradKC<128, 4>::P pa{dy, g, M, K, dyplane}; DmaConvFilterMC<128, 4>::P pb{w, g, C, K, wplane};
       rc = launch_gemm_pw<Pw128, DmaConvDgradKC<128, 4>, DmaConvFilterMC<128, 4>>(pa, pb, ep, M, C, K, 1, stream);
@@ -120,8 +125,13 @@ static int conv_bwd_data_impl(const typename FMT::T* dy, long dyplane, const typ
             rc = launch_gemm_pw<Pw256, DmaConvDgradS2KC<256, 8>, DmaConvFilterS2MC<256, 8>>(pa, pb, e2, Ms, C, Ks, 1, stream);
           } else return CXRK_ERR_UNSUPPORTED;
         } else if (C <= 64) {
-          typename ConvDgradS2KC<256, FMT>::P pa{dy, g, t, Hs, Ws, Ms, Ks, dyplane}; typename ConvFilterS2MC<64, FMT>::P pb{w, g, t, C, Ks, wplane};
-          rc = launch_gemm<ConvDgradS2KC<256, FMT>, ConvFilterS2MC<64, FMT>, 4, 1>(pa, pb, e2, Ms, C, Ks, 1, stream);
+          if constexpr (FMT::PLANES) {
+            DmaConvDgradS2KC<256, 4>::P pa{dy, g, t, Hs, Ws, Ms, Ks, dyplane}; DmaConvFilterS2MC<64, 4>::P pb{w, g, t, C, Ks, wplane};
+            rc = launch_gemm_pw<Pw256x64, DmaConvDgradS2KC<256, 4>, DmaConvFilterS2MC<64, 4>>(pa, pb, e2, Ms, C, Ks, 1, stream);
+          } else {
+            typename ConvDgradS2KC<256, FMT>::P pa{dy, g, t, Hs, Ws, Ms, Ks, dyplane}; typename ConvFilterS2MC<64, FMT>::P pb{w, g, t, C, Ks, wplane};
+            rc = launch_gemm<ConvDgradS2KC<256, FMT>, ConvFilterS2MC<64, FMT>, 4, 1>(pa, pb, e2, Ms, C, Ks, 1, stream);
+          }
         } else if constexpr (FMT::PLANES) {
           DmaConvDgradS2KC<128, 4>::P pa{dy, g, t, Hs, Ws, Ms, Ks, dyplane}; DmaConvFilterS2MC<128, 4>::P pb{w, g, t, C, Ks, wplane};
           rc = launch_gemm_pw<Pw128, DmaConvDgradS2KC<128, 4>, DmaConvFilterS2MC<128, 4>>(pa, pb, e2, Ms, C, Ks, 1, stream);

@@ -25,8 +25,13 @@ static int conv_fwd_impl(const typename FMT::T* x, long xplane, const typename F
     } else return CXRK_ERR_UNSUPPORTED;
   } else if (tapwise) {
     if (Ko <= 64) {
-      typename ConvIm2colKC<256, FMT>::P pa{x, g, M, K, xplane}; typename DenseKC<64, FMT>::P pb{w, (long)K, Ko, K, wplane};
-      rc = launch_gemm<ConvIm2colKC<256, FMT>, DenseKC<64, FMT>, 4, 1>(pa, pb, ep, M, Ko, K, 1, stream);
+      if constexpr (FMT::PLANES) {
+        DmaConvIm2colKC<256, 4>::P pa{x, g, M, K, xplane}; DmaDenseKC<64, 4>::P pb{w, (long)K, Ko, K, wplane};
+        rc = launch_gemm_pw<Pw256x64, DmaConvIm2colKC<256, 4>, DmaDenseKC<64, 4>>(pa, pb, ep, M, Ko, K, 1, stream);
+      } else {
+        typename ConvIm2colKC<256, FMT>::P pa{x, g, M, K, xplane}; typename DenseKC<64, FMT>::P pb{w, (long)K, Ko, K, wplane};
+        rc = launch_gemm<ConvIm2colKC<256, FMT>, DenseKC<64, FMT>, 4, 1>(pa, pb, ep, M, Ko, K, 1, stream);
+      }
     } else if constexpr (FMT::PLANES) {
       DmaConvIm2colKC<128, 4>::P pa{x, g, M, K, xplane}; DmaDenseKC<128, 4>::P pb{w, (long)K, Ko, K, wplane};
       rc = launch_gemm_pw<Pw128, DmaConvIm2colKC<128, 4>, DmaDenseKC<128, 4>>(pa, pb, ep, M, Ko, K, 1, stream);

@@ -125,8 +125,13 @@ static int conv_bwd_params_impl(const typename FMT::T* x, long xplane, const typ
       rc = launch_gemm_pw<Pw256, DmaDenseMC<256, 8>, DmaConvIm2colMC<256, 8>>(pa, pb, ep, Ko, Nc, Kred, sk, stream);
     } else return CXRK_ERR_UNSUPPORTED;
   } else if (Ko <= 64) {
-    typename DenseMC<64, FMT>::P pa{dy, (long)Ko, Ko, Kred, dyplane}; typename ConvIm2colMC<256, FMT>::P pb{x, g, Nc, Kred, xplane};
-    rc = launch_gemm<DenseMC<64, FMT>, ConvIm2colMC<256, FMT>, 1, 4>(pa, pb, ep, Ko, Nc, Kred, sk, stream, exact);
+    if constexpr (FMT::PLANES) {
+      DmaDenseMC<64, 4>::P pa{dy, (long)Ko, Ko, Kred, dyplane}; DmaConvIm2colMC<256, 4>::P pb{x, g, Nc, Kred, xplane};
+      rc = launch_gemm_pw<Pw64x256, DmaDenseMC<64, 4>, DmaConvIm2colMC<256, 4>>(pa, pb, ep, Ko, Nc, Kred, sk, stream);
+    } else {
+      typename DenseMC<64, FMT>::P pa{dy, (long)Ko, Ko, Kred, dyplane}; typename ConvIm2colMC<256, FMT>::P pb{x, g, Nc, Kred, xplane};
+      rc = launch_gemm<DenseMC<64, FMT>, ConvIm2colMC<256, FMT>, 1, 4>(pa, pb, ep, Ko, Nc, Kred, sk, stream, exact);
+    }
   } else if constexpr (FMT::PLANES) {
     DmaDenseMC<128, 4>::P pa{dy, (long)Ko, Ko, Kred, dyplane}; DmaConvIm2colMC<128, 4>::P pb{x, g, Nc, Kred, xplane};
     rc = launch_gemm_pw<Pw128, DmaDenseMC<128, 4>, DmaConvIm2colMC<128, 4>>(pa, pb, ep, Ko, Nc, Kred, sk, stream);

@@ -1,11 +1,10 @@
-// Dense GEMM entry point on split-bf16 planes tensors (the encoders in split-bf16 mode): 256x256 LDS-DMA kernel where the policy
-// picks it, 128x128-class tiles otherwise.
+// Dense GEMM entry point on split-bf16 planes tensors (the encoders in split-bf16 mode), always on the LDS-DMA pipelined kernel
+// (gemm_pw.h): 256x256 tiles where the policy picks them, 256x64 / 64x256 for outputs with <= 64 columns / rows, 128x128 otherwise.
 #include "gemm_common.h"
 
 using namespace cxrk;
 
-template <template <int, class, int> class LAT, template <int, class, int> class LBT, template <int, int> class DLA,
-          template <int, int> class DLB>
+template <template <int, int> class DLA, template <int, int> class DLB>
 static int dense_planes(const unsigned short* A, long lda, long aplane, const unsigned short* B, long ldb, long bplane, const EpiParams& ep,
                         int M, int N, int K, int splitk, hipStream_t stream) {
   if (use_wide256(M, N, K, splitk, true)) {
@@ -13,12 +12,12 @@ static int dense_planes(const unsigned short* A, long lda, long aplane, const un
     return launch_gemm_pw<Pw256, DLA<256, 8>, DLB<256, 8>>(pa, pb, ep, M, N, K, splitk, stream);
   }
   if (N <= 64) {
-    typename LAT<256, PL, NTHREADS>::P pa{A, lda, M, K, aplane}; typename LBT<64, PL, NTHREADS>::P pb{B, ldb, N, K, bplane};
-    return launch_gemm<LAT<256, PL, NTHREADS>, LBT<64, PL, NTHREADS>, 4, 1>(pa, pb, ep, M, N, K, splitk, stream);
+    typename DLA<256, 4>::P pa{A, lda, M, K, aplane}; typename DLB<64, 4>::P pb{B, ldb, N, K, bplane};
+    return launch_gemm_pw<Pw256x64, DLA<256, 4>, DLB<64, 4>>(pa, pb, ep, M, N, K, splitk, stream);
   }
   if (M <= 64) {
-    typename LAT<64, PL, NTHREADS>::P pa{A, lda, M, K, aplane}; typename LBT<256, PL, NTHREADS>::P pb{B, ldb, N, K, bplane};
-    return launch_gemm<LAT<64, PL, NTHREADS>, LBT<256, PL, NTHREADS>, 1, 4>(pa, pb, ep, M, N, K, splitk, stream);
+    typename DLA<64, 4>::P pa{A, lda, M, K, aplane}; typename DLB<256, 4>::P pb{B, ldb, N, K, bplane};
+    return launch_gemm_pw<Pw64x256, DLA<64, 4>, DLB<256, 4>>(pa, pb, ep, M, N, K, splitk, stream);
   }
   typename DLA<128, 4>::P pa{A, lda, M, K, aplane}; typename DLB<128, 4>::P pb{B, ldb, N, K, bplane};
   return launch_gemm_pw<Pw128, DLA<128, 4>, DLB<128, 4>>(pa, pb, ep, M, N, K, splitk, stream);
@@ -59,9 +58,9 @@ extern "C" int cxrk_gemm_pl(int transA, int transB, int M, int N, int K, const v
   const unsigned short* Ap = static_cast<const unsigned short*>(A);
   const unsigned short* Bp = static_cast<const unsigned short*>(B);
   int rc;
-  if (!transA && transB) rc = dense_planes<DenseKC, DenseKC, DmaDenseKC, DmaDenseKC>(Ap, lda, aplane, Bp, ldb, bplane, ep, M, N, K, splitk, stream);
-  else if (!transA && !transB) rc = dense_planes<DenseKC, DenseMC, DmaDenseKC, DmaDenseMC>(Ap, lda, aplane, Bp, ldb, bplane, ep, M, N, K, splitk, stream);
-  else rc = dense_planes<DenseMC, DenseMC, DmaDenseMC, DmaDenseMC>(Ap, lda, aplane, Bp, ldb, bplane, ep, M, N, K, splitk, stream);
+  if (!transA && transB) rc = dense_planes<DmaDenseKC, DmaDenseKC>(Ap, lda, aplane, Bp, ldb, bplane, ep, M, N, K, splitk, stream);
+  else if (!transA && !transB) rc = dense_planes<DmaDenseKC, DmaDenseMC>(Ap, lda, aplane, Bp, ldb, bplane, ep, M, N, K, splitk, stream);
+  else rc = dense_planes<DmaDenseMC, DmaDenseMC>(Ap, lda, aplane, Bp, ldb, bplane, ep, M, N, K, splitk, stream);
   return finish_splitk(rc, splitk, M, N, ws, C, ldc, alpha, accumulate, stream);
 }
 

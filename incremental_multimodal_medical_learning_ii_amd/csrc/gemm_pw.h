@@ -463,6 +463,8 @@ struct PwCfg {
 };
 typedef PwCfg<2, 4, 4> Pw256;   // 256 x 256, 8 waves, 128 KiB LDS, one block per CU
 typedef PwCfg<2, 2, 2> Pw128;   // 128 x 128, 4 waves,  64 KiB LDS, two blocks per CU
+typedef PwCfg<4, 1, 2> Pw256x64;   // 256 x 64 (outputs of <= 64 columns), 4 waves, 80 KiB LDS, two blocks per CU
+typedef PwCfg<1, 4, 2> Pw64x256;   // 64 x 256 (<= 64 rows: weight gradients of <= 64 filters), 4 waves, 80 KiB LDS, two blocks per CU
 
 struct PwFrag { bf16x8 h[2], l[2]; };   // two 32-row (or 32-column) blocks of an operand, hi / lo
 
@@ -567,7 +569,7 @@ __global__ __launch_bounds__(CFG::NT, CFG::WAVES_PER_SIMD) void gemm_pw_kernel(t
       // group 1: rows 64-127, k-step 0
       pw_read<LA>(A0, st, PA, arow, 1, lane);
       pw_read<LB>(B1, st + 2 * PA, PB, bcol, 1, lane);
-      if (!EARLY) PW_LOOP_ISSUE(lb)(k0 + BK, nx + 2 * PA, more);
+      if (!EARLY) PW_LOOP_ISSUE(lb)(k0 + BK, nx + 2 * PA, more);   // (both in group 0: 3683 vs 3605 cycles per K-tile, r2n)
       PW_FENCE();
       pw_mfma12(acc1, A1, B0);
       PW_FENCE();

@@ -171,15 +171,14 @@ def _kern(flops: float, exact: bool = False) -> str:
 
 def _label(la: str, lb: str, tile: str, M: int, N: int, K: int, splitk: int, kind: int, exact: bool = False,
            planes: bool = False) -> str:
-    """Profiler key of a launch: mainloop<A loader,B loader,tile>.  Planes operands take the LDS-DMA pipelined kernel — 256x256
-    tiles when the library's policy picks them, 128x128 (two blocks per CU) otherwise — except where one tile dimension is
-    <= 64, which stays on the register-staged split-bf16 mainloop (256x64 / 64x256 tiles)."""
+    """Profiler key of a launch: mainloop<A loader,B loader,tile>.  Planes operands take the LDS-DMA pipelined kernel: 256x256
+    tiles when the library's policy picks them, 256x64 / 64x256 (two blocks per CU) where the output has <= 64 columns / rows,
+    128x128 (two blocks per CU) otherwise."""
     if planes:
         if _lib.load().cxrk_gemm_wide_tile(M, N, K, splitk, kind):
             return f"gemm_pw_kernel<Pw256,Dma{la},Dma{lb}>"
-        if tile == "2,2":
-            return f"gemm_pw_kernel<Pw128,Dma{la},Dma{lb}>"
-        return f"gemm_x3_kernel<{la}<PL>,{lb}<PL>,{tile}>"
+        cfg = {"2,2": "Pw128", "4,1": "Pw256x64", "1,4": "Pw64x256"}[tile]
+        return f"gemm_pw_kernel<{cfg},Dma{la},Dma{lb}>"
     return f"{_kern(2.0 * M * N * K, exact)}<{la},{lb},{tile}>"
 
 
@@ -686,7 +685,9 @@ def residual_ln_fwd(x, res, gamma, beta, eps, save: bool = True, out_planes: boo
     return y, xhat, rstd
 
 
-def residual_ln_bwd(dy, xhat, rstd, gamma, dgamma, dbeta, dx_add=None, accumulate: bool = False, out=None, out_planes: bool = False):
+def residual_ln_bwd(dy, xhat, rstd, gamma, dgamma, dbeta, dx_add=None, accumulate: bool = False, out=None, out_planes: bool = False,
+                    dxsum=None, dxsum_accumulate: bool = False):
+    """LayerNorm backward (+ dx_add); `dxsum` ([H], optional) receives the column sums of the returned gradient in the same pass."""
     lib = _lib.load()
     rows, H = dy.shape
     if out is None:
@@ -698,7 +699,8 @@ def residual_ln_bwd(dy, xhat, rstd, gamma, dgamma, dbeta, dx_add=None, accumulat
     wsb = lib.cxrk_residual_ln_bwd_ws_bytes(rows, H)
     ws = workspace(wsb, dy.device)
     check(lib.cxrk_residual_ln_bwd(_p(_chk(dy, "ln.dy")), _p(xhat), _p(rstd), _p(gamma), rows, H, _p(dx_add), dxp, dxpl,
-                                   _p(dgamma), _p(dbeta), int(accumulate), _p(ws), ws.numel() * 4, _stream()),
+                                   _p(dgamma), _p(dbeta), int(accumulate), _p(dxsum), int(dxsum_accumulate), _p(ws), ws.numel() * 4,
+                                   _stream()),
           "cxrk_residual_ln_bwd")
     return dx
 

@@ -231,31 +231,35 @@ def _backward(p: Sequence[torch.Tensor], ids: torch.Tensor, n_layers: int, n_hea
         wqkv_w, wo_w, wi_w, wo2_w = wl[i]
         s = saved[i]
 
-        def ln_bwd(dy, xhat, rstd, gamma, jg):
+        def ln_bwd(dy, xhat, rstd, gamma, jg, jbias):
+            """LayerNorm backward; the bias gradient of the dense layer in front of it (parameter jbias) is the column sum of the
+            result and comes out of the same kernel."""
             (dg, a1), (db, a2) = sink.dst(jg), sink.dst(jg + 1)
             if a1 != a2:
                 (dg, a1), (db, a2) = sink.dst(jg, True), sink.dst(jg + 1, True)
-            return K.residual_ln_bwd(dy, xhat, rstd, gamma, dg, db, accumulate=a1, out_planes=pl)
+            bg, bacc = sink.dst(jbias)
+            return K.residual_ln_bwd(dy, xhat, rstd, gamma, dg, db, accumulate=a1, out_planes=pl, dxsum=bg, dxsum_accumulate=bacc)
 
-        def wb(dy, x_in, jw):   # weight + bias gradient of a dense layer
+        def wb(dy, x_in, jw, bias: bool = True):   # weight (+ bias) gradient of a dense layer
             g, acc = sink.dst(jw)
             _wgrad(dy, x_in, g, acc, pl)
-            g, acc = sink.dst(jw + 1)
-            K.colsum(dy, g, accumulate=acc)
+            if bias:
+                g, acc = sink.dst(jw + 1)
+                K.colsum(dy, g, accumulate=acc)
 
-        dt2 = ln_bwd(dx, s.xhat2, s.rstd2, g2, o + 14)
-        wb(dt2, s.u, o + 12)
+        dt2 = ln_bwd(dx, s.xhat2, s.rstd2, g2, o + 14, o + 13)
+        wb(dt2, s.u, o + 12, bias=False)
         du = _dgrad(dt2, wo2_w, pl, aux=s.u_pre, auxmode=K.AUX_GELU_GRAD, out_planes=True)
         wb(du, s.a, o + 10)
         da = _dgrad(du, wi_w, pl, residual=dt2)
-        dt1 = ln_bwd(da, s.xhat1, s.rstd1, g1, o + 8)
+        dt1 = ln_bwd(da, s.xhat1, s.rstd1, g1, o + 8, o + 7)
         rows_cls = cls_only and i == n_layers - 1
         if rows_cls:   # dt1 holds the CLS rows only: its context rows are row 0 of every sequence, all other rows get no gradient
-            wb(dt1, _cls_rows(s.ctx, N, L, H), o + 6)
+            wb(dt1, _cls_rows(s.ctx, N, L, H), o + 6, bias=False)
             dctx = torch.zeros(T, H, dtype=torch.float32, device=dev)
             _dgrad(dt1, wo_w, pl, out=dctx.view(N, L * H)[:, :H])
         else:
-            wb(dt1, s.ctx, o + 6)
+            wb(dt1, s.ctx, o + 6, bias=False)
             dctx = _dgrad(dt1, wo_w, pl)
         dqkv = K.attn_bwd(s.qkv, s.probs, dctx, N, L, n_heads, H // n_heads, out_planes=pl)
         # fused q/k/v gradients: one [3H, H] GEMM into the three (adjacent) .grad slices when they are adjacent too

@@ -12,7 +12,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 def key(k):
     m = re.search(r"gemm_pw_kernel<cxrk::PwCfg<(\d), (\d), (\d)>, cxrk::(\w+)<[^>]*>, cxrk::(\w+)<[^>]*>\s*>", k)
     if m:
-        return f"gemm_pw_kernel<{'Pw256' if m.group(3) == '4' else 'Pw128'},{m.group(4)},{m.group(5)}>"
+        cfg = {"244": "Pw256", "222": "Pw128", "412": "Pw256x64", "142": "Pw64x256"}.get(m.group(1) + m.group(2) + m.group(3), "Pw?")
+        return f"gemm_pw_kernel<{cfg},{m.group(4)},{m.group(5)}>"
     m = re.search(r"(gemm_x3_kernel)<cxrk::(\w+)<\d+, cxrk::PL[^>]*>, cxrk::(\w+)<\d+, cxrk::PL[^>]*>\s*, (\d), (\d)\s*>", k)
     if m:
         return f"{m.group(1)}<{m.group(2)}<PL>,{m.group(3)}<PL>,{m.group(4)},{m.group(5)}>"

@@ -11,9 +11,9 @@ def short(name: str) -> str:
     loaders = re.findall(r"(Dma\w+|\w+[KM]C)(?:<(\d+), (F32|PL)[^>]*>)?", args)
     tile = re.search(r">?, (\d), (\d)$", args)
     parts = [f"{a}{'<' + f + '>' if f == 'PL' else ''}" for a, _, f in loaders[:2]]
-    cfg = re.search(r"PwCfg<\d, \d, (\d)>", args)
+    cfg = re.search(r"PwCfg<(\d), (\d), (\d)>", args)
     if cfg:
-        parts.insert(0, "Pw256" if cfg.group(1) == "4" else "Pw128")
+        parts.insert(0, {"244": "Pw256", "222": "Pw128", "412": "Pw256x64", "142": "Pw64x256"}.get("".join(cfg.groups()), "Pw?"))
     return f"{m.group(1)}<{','.join(parts)}{',' + tile.group(1) + 'x' + tile.group(2) if tile else ''}>"
 
 

@@ -401,6 +401,13 @@ def test_layernorm_fwd_bwd(H):
         close(yp.float(), y, what="ln fwd -> planes")
         dxp = K.residual_ln_bwd(gy.to(DEV), xhat, rstd, g.detach().to(DEV), dg, db, out_planes=True)
         close(dxp.float(), s.grad, what="ln dx -> planes")
+        # fused column sums of the result (bias gradient of the dense layer in front of the LayerNorm), fresh and accumulated
+        bsum = torch.full((H,), 7.0, device=DEV)
+        K.residual_ln_bwd(gy.to(DEV), xhat, rstd, g.detach().to(DEV), dg, db, dx_add=add.to(DEV), out_planes=True, dxsum=bsum)
+        close(bsum, (s.grad + add).sum(0), what="ln fused column sums")
+        K.residual_ln_bwd(gy.to(DEV), xhat, rstd, g.detach().to(DEV), dg, db, dx_add=add.to(DEV), dxsum=bsum, dxsum_accumulate=True)
+        close(bsum, 2 * (s.grad + add).sum(0), what="ln fused column sums, accumulated")
+        close(dg, g.grad, what="ln dgamma beside the fused sums")
 
 
 def test_embed_ln_and_scatter():
