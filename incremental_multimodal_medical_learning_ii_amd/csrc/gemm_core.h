@@ -503,6 +503,8 @@ static inline bool prep_epilogue(EpiParams& e, int M, int N, int splitk) {
   e.fast = e.vec && (N % 8) == 0 && ok8(e.Cp, e.ldc) && ok8(e.Rp, e.ldr) && (e.cplane % 8) == 0 && (e.rplane % 8) == 0 &&
            (!e.maskout || ((N % 64) == 0 && (e.ldmaskout % 8) == 0 && (((uintptr_t)e.maskout) & 7) == 0));
   e.kind = epi_kind(epi_flags(e));
+  // fp32-output feature sets use the 4 + 4 column lane map, whose two column groups must be inside or outside the tensor together
+  if (e.kind >= 0 && (EPI_KINDS[e.kind] & (EF_OUTPL | EF_AUX_MASK | EF_MASKOUT)) == 0u && (N % 64) != 0) e.kind = -1;
   if (e.pl) {   // planes / mask operands exist in the fast epilogue only
     if (!e.fast) return false;
     if ((e.C != nullptr) == (e.Cp != nullptr)) return false;           // exactly one output format

@@ -92,6 +92,11 @@ __device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, unsigned v
   if (nt) __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)voff, 0, 2);   // aux 2 = nt
   else __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)voff, 0, 0);
 }
+__device__ __forceinline__ uint2 buf_load8(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 u = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, 0));
+  return make_uint2(u[0], u[1]);
+}
 __device__ __forceinline__ uint4 f4_bits(float a, float b, float c, float d) {
   return make_uint4(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
 }
@@ -112,14 +117,25 @@ __device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, 
 
   const int r = lane & 31, h = lane >> 5;
   const int c8 = lane & 7, rq = lane >> 3;
-  const int col = col0 + c8 * 8;
-  const bool colok = col < N;
-  const unsigned deadcol = colok ? 0u : VOFF_OOB;
+  // Lane -> columns of the 64-wide sub-tile.  v[0..3] are columns cA..cA+3, v[4..7] columns cB..cB+3.
+  //   planes output / bit masks: cA = 8*c8, cB = cA + 4 — 8 consecutive columns, one 16-byte piece of each bf16 plane (one mask byte);
+  //   fp32 output (MAPF):        cA = 4*c8, cB = 32 + 4*c8 — each store instruction then writes 128 contiguous bytes per row
+  //   (8 lanes x 16 B) instead of every other 16 bytes of 256 (two half-filled lines per row and instruction: measured 19-25 k
+  //   cycles per 256x256 tile against 11.7 k for the planes form with the same number of stores).
+  //   The second group is a CONSTANT byte distance behind the first (DB4 in an fp32 row, DB2 in a bf16 plane row), which the
+  //   compiler folds into the instruction's immediate offset: one offset register per (pass, tensor), as before.  For that both
+  //   groups of a lane must be inside or outside the tensor together: N % 8 == 0 gives it to the 8-column map, and the host
+  //   selects a MAPF feature set only when N % 64 == 0 (prep_epilogue; other widths run the generic form).
+  constexpr bool MAPF = !GEN && (F & (EF_OUTPL | EF_AUX_MASK | EF_MASKOUT)) == 0u;
+  constexpr unsigned DB4 = MAPF ? 128u : 16u, DB2 = 64u;
+  const int cA = MAPF ? c8 * 4 : c8 * 8, cB = MAPF ? 32 + c8 * 4 : c8 * 8 + 4;
+  const unsigned deadA = col0 + cA < N ? 0u : VOFF_OOB;
 
   float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (has_bias) {
     const __amdgpu_buffer_rsrc_t rb = tile_rsrc(ep.bias + col0);
-    const uint4 b0 = buf_load16(rb, (unsigned)(c8 * 32) | deadcol), b1 = buf_load16(rb, (unsigned)(c8 * 32 + 16) | deadcol);
+    const unsigned ob = (unsigned)(cA * 4) | deadA;
+    const uint4 b0 = buf_load16(rb, ob), b1 = buf_load16(rb, ob + DB4);
     bv[0] = __builtin_bit_cast(float, b0.x); bv[1] = __builtin_bit_cast(float, b0.y); bv[2] = __builtin_bit_cast(float, b0.z); bv[3] = __builtin_bit_cast(float, b0.w);
     bv[4] = __builtin_bit_cast(float, b1.x); bv[5] = __builtin_bit_cast(float, b1.y); bv[6] = __builtin_bit_cast(float, b1.z); bv[7] = __builtin_bit_cast(float, b1.w);
   }
@@ -138,7 +154,6 @@ __device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, 
   const __amdgpu_buffer_rsrc_t d_c2 = tile_rsrc(ep.C2 + rbase * ep.ldc2 + col0, has_c2);
   const __amdgpu_buffer_rsrc_t d_min = tile_rsrc(ep.maskin + rbase * ep.ldmaskin + (col0 >> 3), aux_mask);
   const __amdgpu_buffer_rsrc_t d_mout = tile_rsrc(ep.maskout + rbase * ep.ldmaskout + (col0 >> 3), maskout);
-  const unsigned osz = outpl ? 2u : 4u;
 
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -150,7 +165,9 @@ __device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, 
 
     // ---- side inputs of PF 8-row passes at a time (all four of this half in the compiled-in feature sets; the generic form, which
     //      may carry every side input at once, goes pass by pass to stay inside the register budget)
-    constexpr int PF = GEN ? 1 : 4;
+    // (an fp32 residual AND an fp32 aux tensor — the fp32-mode data gradient with identity branch — are four 16-byte loads per pass:
+    //  two passes ahead is what the 168-register budget of the three-blocks-per-CU kernels holds without spilling)
+    constexpr int PF = GEN ? 1 : (((F & EF_RES_F32) != 0u && (F & (EF_AUX_SIGN | EF_AUX_GELU)) != 0u) ? 2 : 4);
 #pragma unroll
     for (int ug = 0; ug < 4; ug += PF) {
     unsigned dead[PF]; long rows[PF];
@@ -160,28 +177,34 @@ __device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, 
       const int u = up, ua = ug + up;
       const int rl = i * 32 + ua * 8 + rq;              // row inside the sub-tile
       const int grow = row0 + rl;
-      dead[u] = (grow < M ? 0u : VOFF_OOB) | deadcol;
+      dead[u] = grow < M ? 0u : VOFF_OOB;   // row only; the column part (deadA / deadB) is OR-ed in per access
       rows[u] = remap ? epi_row(ep, grow < M ? grow : M - 1) - rbase : (long)rl;
       const unsigned rowo = (unsigned)rows[u];
       if (res_pl) {
-        const unsigned o = ((rowo * (unsigned)ep.ldr + c8 * 8) * 2u) | dead[u];
-        r0v[u] = buf_load16(d_res, o); r1v[u] = buf_load16(d_res2, o);
+        if constexpr (MAPF) {   // 4 + 4 columns: two 8-byte pieces of each plane
+          const unsigned oa = ((rowo * (unsigned)ep.ldr + cA) * 2u) | dead[u] | deadA;
+          const uint2 ha = buf_load8(d_res, oa), hb = buf_load8(d_res, oa + DB2), la = buf_load8(d_res2, oa), lb = buf_load8(d_res2, oa + DB2);
+          r0v[u] = make_uint4(ha.x, ha.y, hb.x, hb.y); r1v[u] = make_uint4(la.x, la.y, lb.x, lb.y);
+        } else {
+          const unsigned o = ((rowo * (unsigned)ep.ldr + cA) * 2u) | dead[u] | deadA;
+          r0v[u] = buf_load16(d_res, o); r1v[u] = buf_load16(d_res2, o);
+        }
       } else if (res_f32) {
-        const unsigned o = ((rowo * (unsigned)ep.ldr + c8 * 8) * 4u) | dead[u];
-        r0v[u] = buf_load16(d_res, o); r1v[u] = buf_load16(d_res, o + 16u);
+        const unsigned o = ((rowo * (unsigned)ep.ldr + cA) * 4u) | dead[u] | deadA;
+        r0v[u] = buf_load16(d_res, o); r1v[u] = buf_load16(d_res, o + DB4);
       }
       if (aux_sign || aux_gelu) {
-        const unsigned o = ((rowo * (unsigned)ep.ldaux + c8 * 8) * 4u) | dead[u];
-        a0v[u] = buf_load16(d_aux, o); a1v[u] = buf_load16(d_aux, o + 16u);
+        const unsigned o = ((rowo * (unsigned)ep.ldaux + cA) * 4u) | dead[u] | deadA;
+        a0v[u] = buf_load16(d_aux, o); a1v[u] = buf_load16(d_aux, o + DB4);
       }
-      if (aux_mask) mk[u] = __builtin_amdgcn_raw_buffer_load_b8(d_min, (int)((rowo * (unsigned)ep.ldmaskin + c8) | dead[u]), 0, 0);
+      if (aux_mask) mk[u] = __builtin_amdgcn_raw_buffer_load_b8(d_min, (int)((rowo * (unsigned)ep.ldmaskin + c8) | dead[u] | deadA), 0, 0);
     }
     // ---- values, stores
 #pragma unroll
     for (int up = 0; up < PF; ++up) {
       const int u = up, ua = ug + up;
-      const float* sp = st + (ua * 8 + rq) * 64 + c8 * 8;
-      const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+      const float* sp = st + (ua * 8 + rq) * 64;
+      const float4 s0 = *reinterpret_cast<const float4*>(sp + cA), s1 = *reinterpret_cast<const float4*>(sp + cB);
       float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
       const unsigned rowo = (unsigned)rows[u];
 #pragma unroll
@@ -196,9 +219,9 @@ __device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, 
         for (int q = 0; q < 8; ++q) v[q] += __builtin_bit_cast(float, rw[q]);
       }
       if (has_c2) {
-        const unsigned o = ((rowo * (unsigned)ep.ldc2 + c8 * 8) * 4u) | dead[u];
+        const unsigned o = ((rowo * (unsigned)ep.ldc2 + cA) * 4u) | dead[u] | deadA;
         buf_store16(d_c2, o, f4_bits(v[0], v[1], v[2], v[3]), false);
-        buf_store16(d_c2, o + 16u, f4_bits(v[4], v[5], v[6], v[7]), false);
+        buf_store16(d_c2, o + DB4, f4_bits(v[4], v[5], v[6], v[7]), false);
       }
       unsigned obits = 0;
       if (relu) {
@@ -221,18 +244,19 @@ __device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, 
           for (int q = 0; q < 8; ++q) v[q] *= gelu_erf_grad(__builtin_bit_cast(float, aw[q]));
         }
       }
-      if (colsum) {
+      if (colsum) {   // rows outside the tensor contribute nothing (dead columns are dropped at the final store)
         const bool livel = dead[u] == 0u;
 #pragma unroll
         for (int q = 0; q < 8; ++q) bs[q] += livel ? v[q] : 0.f;
       }
-      const unsigned oo = ((rowo * (unsigned)ep.ldc + c8 * 8) * osz) | dead[u];
       if (outpl) {
+        const unsigned oo = ((rowo * (unsigned)ep.ldc + cA) * 2u) | dead[u] | deadA;
         uint4 hv, lv; planes_pack8(v, hv, lv);
         buf_store16(d_out, oo, hv, nt); buf_store16(d_out2, oo, lv, nt);
       } else {
+        const unsigned oo = ((rowo * (unsigned)ep.ldc + cA) * 4u) | dead[u] | deadA;
         buf_store16(d_out, oo, f4_bits(v[0], v[1], v[2], v[3]), nt);
-        buf_store16(d_out, oo + 16u, f4_bits(v[4], v[5], v[6], v[7]), nt);
+        buf_store16(d_out, oo + DB4, f4_bits(v[4], v[5], v[6], v[7]), nt);
       }
       if (maskout) {   // the 8 lanes of a row hold its 8 mask bytes: OR them together, lane c8 == 0 stores the 8 bytes
         unsigned w0 = c8 < 4 ? obits << (8 * c8) : 0u, w1 = c8 >= 4 ? obits << (8 * (c8 - 4)) : 0u;
@@ -256,9 +280,10 @@ __device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, 
       bs[q] = t;
     }
     const __amdgpu_buffer_rsrc_t d_cs = tile_rsrc(ep.colsum_part + (long)part * N + col0);
-    const unsigned o = (unsigned)(c8 * 32) | ((rq == 0 && colok) ? 0u : VOFF_OOB);
+    const unsigned keep = rq == 0 ? 0u : VOFF_OOB;
+    const unsigned o = (unsigned)(cA * 4) | keep | deadA;
     buf_store16(d_cs, o, f4_bits(bs[0], bs[1], bs[2], bs[3]), false);
-    buf_store16(d_cs, o + 16u, f4_bits(bs[4], bs[5], bs[6], bs[7]), false);
+    buf_store16(d_cs, o + DB4, f4_bits(bs[4], bs[5], bs[6], bs[7]), false);
   }
 }
 #undef EH

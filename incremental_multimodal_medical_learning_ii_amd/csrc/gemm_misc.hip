@@ -128,7 +128,8 @@ int cxrk::wgrad_splitk_policy(int M, int N, int K, bool planes) {
   const long maxk = K / (8 * BK) > 0 ? K / (8 * BK) : 1;
   if (planes && wide_mode() != 0 && M >= 256 && N >= 256) {
     const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256);
-    long sk = 512 / tiles;   // floor: two full rounds of 256 blocks at most (one block over would cost a third round)
+    static const long blocks = env_long("CXRK_WGRAD_BLOCKS", 512);   // tuning override
+    long sk = blocks / tiles;   // floor: two full rounds of 256 blocks at most (one block over would cost a third round)
     if (sk > maxk) sk = maxk;
     if (sk < 1) sk = 1;
     if (sk > 512) sk = 512;

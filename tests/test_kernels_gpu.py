@@ -469,6 +469,18 @@ def test_l2norm_infonce_pieces(golden_dir):
     close(diag, S.diag(), what="diag")
 
 
+def test_epilogue_lane_maps_standalone():
+    """csrc/epilogue_check: every compiled-in fp32 feature set of the GEMM epilogue on small / ragged / strided shapes with
+    guard regions around all buffers (a store outside its tensor is reported, not a fault) against a CPU fp64 reference."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(_cxr_lib.__file__), "csrc", "epilogue_check")
+    if not os.path.exists(exe):
+        pytest.fail("csrc/epilogue_check is not built (make -C incremental_multimodal_medical_learning_ii_amd/csrc)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    bad = [ln for ln in r.stdout.splitlines() if ln.startswith("FAIL")]
+    assert r.returncode == 0 and not bad and "0 failing cases" in r.stdout, "\n".join(bad[:10]) + r.stderr[-500:]
+
+
 def test_pairwise_cosine_max_and_patch_similarity_vs_fixture(golden_dir):
     """MAX_EMB head (`Trainer.py:1691-1693`) and the patch-wise similarity GEMV (`vlp/inference_engine.py:104`) against the
     committed G6 vectors (similarity map: outputs of the reference's own static methods; cosine: restatement, parity unpinned)."""
