@@ -76,13 +76,39 @@ class _FlatOptimizer:
                 gv.copy_(p.grad)
                 p.grad = gv
 
-    def all_reduce_grads(self, group=None, bucket_bytes: int = 256 << 20, average: bool = False) -> None:
-        """Sum (or average) the flat gradient buffer over the data-parallel group in large contiguous buckets."""
+    def grad_span(self, params) -> Optional[tuple]:
+        """(lo, hi) element range of the flat gradient buffer that holds exactly the gradients of `params`, or None when they
+        do not form one gap-free range (then only the whole buffer can be reduced at once)."""
+        ids = {id(p) for p in params}
+        base = self.flat_g.data_ptr()
+        lo, hi, tot = None, 0, 0
+        for p, gv in zip(self.params, self._views):
+            if id(p) in ids:
+                o = (gv.data_ptr() - base) // 4
+                n = (p.numel() + 3) // 4 * 4
+                lo = o if lo is None else min(lo, o)
+                hi, tot = max(hi, o + n), tot + n
+        return (lo, hi) if lo is not None and hi - lo == tot else None
+
+    def all_reduce_span(self, lo: int, hi: int, group=None, bucket_bytes: int = 256 << 20) -> list:
+        """Start the sum of flat_g[lo:hi] over the group (async, ordered after the work already queued on the CURRENT stream);
+        returns the work handles for `all_reduce_grads(skip=..., pending=...)` to wait on."""
+        import torch.distributed as dist
+        step = max(1, bucket_bytes // 4)
+        return [dist.all_reduce(self.flat_g[o:min(hi, o + step)], group=group, async_op=True) for o in range(lo, hi, step)]
+
+    def all_reduce_grads(self, group=None, bucket_bytes: int = 256 << 20, average: bool = False, skip: Optional[tuple] = None,
+                         pending: Optional[list] = None) -> None:
+        """Sum (or average) the flat gradient buffer over the data-parallel group in large contiguous buckets.  `skip` = an
+        element range already being reduced by `all_reduce_span` (its handles in `pending`)."""
         import torch.distributed as dist
         self._sync_grads()
         n = self.flat_g.numel()
-        step = max(1, bucket_bytes // 4)
-        works = [dist.all_reduce(self.flat_g[o:o + step], group=group, async_op=True) for o in range(0, n, step)]
+        spans = [(0, n)] if skip is None else [(0, skip[0]), (skip[1], n)]
+        works = list(pending or [])
+        for lo, hi in spans:
+            if hi > lo:
+                works += self.all_reduce_span(lo, hi, group, bucket_bytes)
         for w in works:
             w.wait()
         if average:

@@ -302,6 +302,12 @@ def _backward(p: Sequence[torch.Tensor], ids: torch.Tensor, n_layers: int, n_hea
         K.colsum(demb, dtyp[0], accumulate=acc)
 
 
+# Called at the end of the encoder's backward, on the stream it ran on, when all its parameter gradients were written in place
+# (contrastive.JointContrastiveTrainer: start the gradient all-reduce of the text encoder while the image encoder is still in
+# its backward).  None = nothing to do.
+after_backward = None
+
+
 class CXRBertEncodeFn(torch.autograd.Function):
     """(ids, mask, cfg, cls_only, *params) -> (cls_projected_embedding [N,P], last_hidden_state [N,L,H], or [N,1,H] = its
     CLS rows when cls_only; an empty tensor when the caller does not want it)."""
@@ -335,7 +341,11 @@ class CXRBertEncodeFn(torch.autograd.Function):
         _backward(ctx.p, ctx.ids, n_layers, n_heads, ctx.state, ctx.last, dproj, dlast, sink, cls_only)
         ctx.state = None
         ctx.last = None
-        return (None, None, None, None, None, None, None) + sink.result()
+        res = sink.result()
+        hook = after_backward
+        if hook is not None and all(r is None for r in res):
+            hook()   # every gradient of this encoder already sits in its `.grad` view: the data-parallel step starts reducing them now
+        return (None, None, None, None, None, None, None) + res
 
 
 def encode(params: Sequence[torch.Tensor], ids: torch.Tensor, mask: Optional[torch.Tensor], n_layers: int,
