@@ -122,21 +122,25 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, 
 }  // namespace
 
 // Split-K factor for a weight-gradient shaped GEMM (small M x N output, very long K): enough slabs to fill the chip with
-// the tile the launch will use (256x256, planes operands only: about two rounds of 256 blocks; 128x128: about six blocks per
-// CU), each slab at least 8 K-tiles long.
+// the tile the launch will use (256x256, planes operands only: one round of 256 blocks; 128x128: about six blocks per CU),
+// each slab at least 8 K-tiles long.
 int cxrk::wgrad_splitk_policy(int M, int N, int K, bool planes) {
   const long maxk = K / (8 * BK) > 0 ? K / (8 * BK) : 1;
   if (planes && wide_mode() != 0 && M >= 256 && N >= 256) {
     const long tiles = (long)ceil_div(M, 256) * ceil_div(N, 256);
-    static const long blocks = env_long("CXRK_WGRAD_BLOCKS", 512);   // tuning override
-    long sk = blocks / tiles;   // floor: two full rounds of 256 blocks at most (one block over would cost a third round)
+    // ONE round of 256 blocks (floor: one block over would cost a second round).  Two rounds (512) were the round-1 choice for
+    // the register-staged kernel; with the pipelined kernel half as many, twice as long slabs win: fewer prologues / epilogues
+    // per CU and half the slab traffic of the reduction (r2q: weight-gradient launches 27.3 -> 25.3 ms per step).
+    static const long blocks = env_long("CXRK_WGRAD_BLOCKS", 256);   // tuning override
+    long sk = blocks / tiles;
     if (sk > maxk) sk = maxk;
     if (sk < 1) sk = 1;
     if (sk > 512) sk = 512;
     if (use_wide256(M, N, K, (int)sk, true)) return (int)sk;
   }
   const long tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
-  long sk = (1536 + tiles - 1) / tiles;
+  static const long blocks128 = env_long("CXRK_WGRAD_BLOCKS128", 1536);   // tuning override (128x128-class tiles: ~6 blocks per CU)
+  long sk = (blocks128 + tiles - 1) / tiles;
   if (sk > K / 256) sk = K / 256;
   if (sk > 512) sk = 512;
   if (sk < 1) sk = 1;
