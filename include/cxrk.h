@@ -57,7 +57,8 @@ int cxrk_gemm_pl(int transA, int transB, int M, int N, int K, const void* A, lon
                  long bplane, float* C, void* Cp, long ldc, long cplane, const float* bias, const float* R, const void* Rp,
                  long ldr, long rplane, const float* aux, long ldaux, int auxmode, const unsigned char* maskin, long ldmaskin,
                  unsigned char* maskout, long ldmaskout, float* C2, long ldc2, int act, float alpha, int accumulate, int splitk,
-                 float* ws, size_t ws_bytes, hipStream_t stream);
+                 float* colsum, int colsum_accumulate, float* ws, size_t ws_bytes, hipStream_t stream);
+size_t cxrk_gemm_pl_colsum_ws_bytes(int M, int N);   /* ws for the fused column sums (`colsum` != NULL; needs splitk == 1) */
 /* fp32 tensor -> planes (weights once per step, inputs of the path) and back (host-side consumers, tests); n % 8 == 0. */
 int cxrk_split_planes(const float* x, long n, void* out, long plane, hipStream_t stream);
 int cxrk_merge_planes(const void* x, long plane, long n, float* out, hipStream_t stream);

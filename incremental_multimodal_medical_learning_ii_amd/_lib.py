@@ -19,7 +19,8 @@ P, I, L, F, Z = c_void_p, c_int, c_long, c_float, c_size_t
 SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_gemm_splitk_ws_bytes": (Z, [I, I, I]),
     "cxrk_gemm_f32": (I, [I, I, I, I, I, P, L, P, L, P, L, P, P, L, P, L, I, P, L, I, F, I, I, P, Z, P]),
-    "cxrk_gemm_pl": (I, [I, I, I, I, I, P, L, L, P, L, L, P, P, L, L, P, P, P, L, L, P, L, I, P, L, P, L, P, L, I, F, I, I, P, Z, P]),
+    "cxrk_gemm_pl": (I, [I, I, I, I, I, P, L, L, P, L, L, P, P, L, L, P, P, P, L, L, P, L, I, P, L, P, L, P, L, I, F, I, I, P, I, P, Z, P]),
+    "cxrk_gemm_pl_colsum_ws_bytes": (Z, [I, I]),
     "cxrk_split_planes": (I, [P, L, P, L, P]),
     "cxrk_merge_planes": (I, [P, L, L, P, P]),
     "cxrk_colsum_pl": (I, [P, L, L, L, I, P, F, I, P, Z, P]),

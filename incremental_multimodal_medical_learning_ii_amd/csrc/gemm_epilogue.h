@@ -59,6 +59,7 @@ constexpr unsigned EPI_KINDS[] = {
     EF_BIAS | EF_GELU | EF_C2,                                   // 17 fp32 mode: FFN up projection
     EF_RES_F32,                                                  // 18 fp32 mode: data gradient + residual gradient
     EF_OUTPL | EF_BIAS | EF_RELU,                                // 19 stem conv + BN + ReLU (its mask is the sign of the pooled value)
+    EF_OUTPL | EF_AUX_GELU | EF_COLSUM,                          // 20 gradient through GELU + its column sums (FFN-up bias gradient)
 };
 constexpr int EPI_NKINDS = (int)(sizeof(EPI_KINDS) / sizeof(EPI_KINDS[0]));
 

@@ -23,16 +23,45 @@ static int dense_planes(const unsigned short* A, long lda, long aplane, const un
   return launch_gemm_pw<Pw128, DLA<128, 4>, DLB<128, 4>>(pa, pb, ep, M, N, K, splitk, stream);
 }
 
+// Row tile the dispatch above uses (the fused column sums come as one partial row per 64 output rows of the padded row tiling).
+static int dense_planes_row_tile(int M, int N, int K, int splitk) {
+  if (use_wide256(M, N, K, splitk, true) || N <= 64) return 256;
+  return M <= 64 ? 64 : 128;
+}
+extern "C" size_t cxrk_gemm_pl_colsum_ws_bytes(int M, int N) { return (size_t)(ceil_div(M, 64) + 4) * N * sizeof(float); }
+
+namespace {
+// out[c] (+)= sum_p part[p][c]: 64 columns x 16 part lanes per block, lanes added in order (deterministic)
+__global__ __launch_bounds__(1024) void colsum_parts_kernel(const float* __restrict__ part, int nparts, int N, float* __restrict__ out,
+                                                            int accumulate) {
+  __shared__ float sh[16][64];
+  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float a = 0.f;
+  if (c < N)
+    for (int p = pl; p < nparts; p += 16) a += part[(long)p * N + c];
+  sh[pl][cl] = a;
+  __syncthreads();
+  if (pl == 0 && c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sh[i][cl];
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+}  // namespace
+
 // Same contraction on pre-split ("planes") operands: A and B are bf16 hi/lo plane pairs (lo plane `aplane` / `bplane` elements
 // behind the hi plane), the output is either fp32 (C) or planes (Cp, `cplane`), the residual either fp32 (R) or planes (Rp).
 // auxmode 2 = multiply by gelu'(aux) (aux fp32), 3 = multiply by the ReLU decision bits `maskin` (byte [row][col / 8]);
-// `maskout` (with act 1) receives the decision bits of this launch's own ReLU.
+// `maskout` (with act 1) receives the decision bits of this launch's own ReLU.  `colsum` (optional, [N], no split-K): column sums of
+// the stored output, reduced in the epilogue (per-wave partial rows in `ws`, cxrk_gemm_pl_colsum_ws_bytes) and finished here.
 extern "C" int cxrk_gemm_pl(int transA, int transB, int M, int N, int K, const void* A, long lda, long aplane, const void* B,
                             long ldb, long bplane, float* C, void* Cp, long ldc, long cplane, const float* bias, const float* R,
                             const void* Rp, long ldr, long rplane, const float* aux, long ldaux, int auxmode,
                             const unsigned char* maskin, long ldmaskin, unsigned char* maskout, long ldmaskout, float* C2,
-                            long ldc2, int act, float alpha, int accumulate, int splitk, float* ws, size_t ws_bytes,
-                            hipStream_t stream) {
+                            long ldc2, int act, float alpha, int accumulate, int splitk, float* colsum, int colsum_accumulate,
+                            float* ws, size_t ws_bytes, hipStream_t stream) {
   CXRK_CHECK_ARG(A && B && (C || Cp) && M > 0 && N > 0 && K > 0);
   CXRK_CHECK_ARG(aligned16(A) && aligned16(B) && (lda % 8 == 0) && (ldb % 8 == 0) && (aplane % 8 == 0) && (bplane % 8 == 0));
   CXRK_CHECK_ARG(transA ? (M % 8 == 0) : (K % 8 == 0));
@@ -44,6 +73,10 @@ extern "C" int cxrk_gemm_pl(int transA, int transB, int M, int N, int K, const v
   EpiParams ep{};
   ep.alpha = alpha;
   const bool plain = !bias && !R && !Rp && !aux && !maskin && !maskout && !C2 && act == 0;
+  if (colsum) {
+    CXRK_CHECK_ARG(splitk == 1 && (N % 8) == 0);
+    if (ws == nullptr || ws_bytes < cxrk_gemm_pl_colsum_ws_bytes(M, N)) return CXRK_ERR_WS;
+  }
   if (splitk > 1) {
     CXRK_CHECK_ARG(plain && C && !Cp && (N % 4 == 0));
     if (ws == nullptr || ws_bytes < cxrk_gemm_splitk_ws_bytes(M, N, splitk)) return CXRK_ERR_WS;
@@ -54,6 +87,7 @@ extern "C" int cxrk_gemm_pl(int transA, int transB, int M, int N, int K, const v
     ep.C = C; ep.Cp = static_cast<unsigned short*>(Cp); ep.ldc = ldc; ep.cplane = cplane; ep.bias = bias;
     ep.aux = aux; ep.ldaux = ldaux; ep.auxmode = auxmode; ep.maskin = maskin; ep.ldmaskin = ldmaskin;
     ep.maskout = maskout; ep.ldmaskout = ldmaskout; ep.C2 = C2; ep.ldc2 = ldc2; ep.act = act;
+    ep.colsum_part = colsum ? ws : nullptr;
   }
   const unsigned short* Ap = static_cast<const unsigned short*>(A);
   const unsigned short* Bp = static_cast<const unsigned short*>(B);
@@ -61,6 +95,14 @@ extern "C" int cxrk_gemm_pl(int transA, int transB, int M, int N, int K, const v
   if (!transA && transB) rc = dense_planes<DmaDenseKC, DmaDenseKC>(Ap, lda, aplane, Bp, ldb, bplane, ep, M, N, K, splitk, stream);
   else if (!transA && !transB) rc = dense_planes<DmaDenseKC, DmaDenseMC>(Ap, lda, aplane, Bp, ldb, bplane, ep, M, N, K, splitk, stream);
   else rc = dense_planes<DmaDenseMC, DmaDenseMC>(Ap, lda, aplane, Bp, ldb, bplane, ep, M, N, K, splitk, stream);
+  if (colsum) {
+    if (rc < 0) return rc;
+    const int tm = dense_planes_row_tile(M, N, K, splitk);
+    const int nparts = ceil_div(M, tm) * (tm / 64);
+    hipLaunchKernelGGL(colsum_parts_kernel, dim3(ceil_div(N, 64)), dim3(1024), 0, stream, ws, nparts, N, colsum, colsum_accumulate);
+    CXRK_LAUNCH_CHECK();
+    return CXRK_OK;
+  }
   return finish_splitk(rc, splitk, M, N, ws, C, ldc, alpha, accumulate, stream);
 }
 

@@ -290,9 +290,10 @@ def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accum
 
 def gemm_pl(a: Planes, b: Planes, M: int, N: int, K: int, trans_a: bool, trans_b: bool, out=None, bias=None, residual=None,
             aux=None, auxmode: int = 0, maskin=None, maskout=None, preact_out=None, act: int = 0, alpha: float = 1.0,
-            accumulate: bool = False, splitk: int = 1):
+            accumulate: bool = False, splitk: int = 1, colsum=None, colsum_accumulate: bool = False):
     """The GEMM family on planes operands.  `out`: fp32 tensor or Planes (row-major [M, N]); `residual`: fp32 tensor or Planes;
-    `aux` (auxmode 2): fp32 pre-activation for gelu'; `maskin` (auxmode 3) / `maskout` (with ReLU): uint8 bit masks [M, N/8]."""
+    `aux` (auxmode 2): fp32 pre-activation for gelu'; `maskin` (auxmode 3) / `maskout` (with ReLU): uint8 bit masks [M, N/8];
+    `colsum` ([N], optional, splitk == 1): receives (accumulates) the column sums of the stored output, reduced in the epilogue."""
     lib = _lib.load()
     ap, lda, apl = _pl2d(a, "gemm_pl.a")
     bp, ldb, bpl = _pl2d(b, "gemm_pl.b")
@@ -333,6 +334,14 @@ def gemm_pl(a: Planes, b: Planes, M: int, N: int, K: int, trans_a: bool, trans_b
         wsb = lib.cxrk_gemm_splitk_ws_bytes(M, N, splitk)
         ws = workspace(wsb, a.device)
         wsb = ws.numel() * 4
+    elif colsum is not None:
+        _chk(colsum, "gemm_pl.colsum")
+        if colsum.numel() != N or not colsum.is_contiguous():
+            raise ValueError("gemm_pl.colsum must be contiguous with N elements")
+        ws = workspace(lib.cxrk_gemm_pl_colsum_ws_bytes(M, N), a.device)
+        wsb = ws.numel() * 4
+    if colsum is not None and splitk > 1:
+        raise ValueError("gemm_pl: fused column sums need splitk == 1")
     plain = bias is None and residual is None and aux is None and maskin is None and preact_out is None and act == 0
     ev = profiler.bracket(_label(f"Dense{'MC' if trans_a else 'KC'}", f"Dense{'KC' if trans_b else 'MC'}", _tile(M, N), M, N, K, splitk,
                                  0 if (plain or splitk > 1) else 3, planes=True), 2.0 * M * N * K,
@@ -340,7 +349,7 @@ def gemm_pl(a: Planes, b: Planes, M: int, N: int, K: int, trans_a: bool, trans_b
                                                        + int(bool(accumulate)))) + M * N / 8.0 * ((maskin is not None) + (maskout is not None))) if profiler.on else None
     rc = lib.cxrk_gemm_pl(int(trans_a), int(trans_b), M, N, K, ap, lda, apl, bp, ldb, bpl, C, Cp, ldc, cpl, _p(bias), R, Rp, ldr, rpl,
                           _p(aux), ldaux, auxmode, _p(maskin), ldmi, _p(maskout), ldmo, _p(preact_out), ldc2, act, float(alpha),
-                          int(accumulate), int(splitk), _p(ws), wsb, _stream())
+                          int(accumulate), int(splitk), _p(colsum), int(colsum_accumulate), _p(ws), wsb, _stream())
     if ev is not None:
         ev.record()
     check(rc, f"cxrk_gemm_pl(M={M},N={N},K={K},tA={trans_a},tB={trans_b})")
@@ -360,15 +369,17 @@ def linear_fwd_pl(x: Planes, w: Planes, bias=None, act: int = 0, residual=None, 
 
 
 def linear_bwd_data_pl(dy: Planes, w: Planes, aux=None, auxmode: int = 0, maskin=None, residual=None, out=None,
-                       out_planes: bool = False, accumulate: bool = False):
-    """dx[M,K] = (dy[M,N] @ w[N,K] + residual) (* gelu'(aux) | * mask bits)."""
+                       out_planes: bool = False, accumulate: bool = False, colsum=None, colsum_accumulate: bool = False):
+    """dx[M,K] = (dy[M,N] @ w[N,K] + residual) (* gelu'(aux) | * mask bits); `colsum` ([K], optional) receives the column sums of dx
+    (the bias gradient of the layer that produced this layer's input) from the same epilogue."""
     M, N = dy.shape
     K = w.shape[1]
     if out is None:
         out = Planes.empty(M, K, device=dy.device) if out_planes else torch.empty(M, K, dtype=torch.float32, device=dy.device)
     if maskin is not None:
         auxmode = AUX_MASK_BITS
-    return gemm_pl(dy, w, M, K, N, False, False, out=out, aux=aux, auxmode=auxmode, maskin=maskin, residual=residual, accumulate=accumulate)
+    return gemm_pl(dy, w, M, K, N, False, False, out=out, aux=aux, auxmode=auxmode, maskin=maskin, residual=residual, accumulate=accumulate,
+                   colsum=colsum, colsum_accumulate=colsum_accumulate)
 
 
 def linear_bwd_weight_pl(dy: Planes, x: Planes, dw: torch.Tensor, accumulate: bool = False) -> torch.Tensor:

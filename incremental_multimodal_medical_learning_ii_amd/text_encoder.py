@@ -249,8 +249,13 @@ def _backward(p: Sequence[torch.Tensor], ids: torch.Tensor, n_layers: int, n_hea
 
         dt2 = ln_bwd(dx, s.xhat2, s.rstd2, g2, o + 14, o + 13)
         wb(dt2, s.u, o + 12, bias=False)
-        du = _dgrad(dt2, wo2_w, pl, aux=s.u_pre, auxmode=K.AUX_GELU_GRAD, out_planes=True)
-        wb(du, s.a, o + 10)
+        if pl:   # the FFN-up bias gradient = column sums of du, reduced in the epilogue that writes du
+            bg, bacc = sink.dst(o + 11)
+            du = _dgrad(dt2, wo2_w, pl, aux=s.u_pre, auxmode=K.AUX_GELU_GRAD, out_planes=True, colsum=bg, colsum_accumulate=bacc)
+            wb(du, s.a, o + 10, bias=False)
+        else:
+            du = _dgrad(dt2, wo2_w, pl, aux=s.u_pre, auxmode=K.AUX_GELU_GRAD, out_planes=True)
+            wb(du, s.a, o + 10)
         da = _dgrad(du, wi_w, pl, residual=dt2)
         dt1 = ln_bwd(da, s.xhat1, s.rstd1, g1, o + 8, o + 7)
         rows_cls = cls_only and i == n_layers - 1

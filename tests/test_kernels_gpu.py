@@ -252,6 +252,15 @@ def test_planes_gemm_family(M, N, Kd, wide):
     close(K.linear_bwd_data_pl(dyp, wp, maskin=bits, out_planes=True).float(), (dy @ w) * dec, tol=tol, what="dgrad bit mask")
     out = torch.full((M, Kd), 1.0, device=DEV)
     close(K.linear_bwd_data_pl(dyp, wp, out=out, accumulate=True), dy @ w + 1.0, tol=tol, what="dgrad accumulate")
+    if Kd % 8 == 0:   # column sums of the stored gradient from the same epilogue (generic feature set, and the compiled-in GELU' one)
+        cs = torch.full((Kd,), 3.0, device=DEV)
+        K.linear_bwd_data_pl(dyp, wp, out_planes=True, colsum=cs)
+        close(cs, (dy @ w).sum(0), tol=tol * 4, what="dgrad fused column sums")
+        pre = rnd(M, Kd, seed=12)
+        gp = 0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
+        dxg = K.linear_bwd_data_pl(dyp, wp, aux=pre.to(DEV), auxmode=K.AUX_GELU_GRAD, out_planes=True, colsum=cs, colsum_accumulate=True)
+        close(dxg.float(), (dy @ w) * gp, tol=tol, what="dgrad through gelu'")
+        close(cs, (dy @ w).sum(0) + ((dy @ w) * gp).sum(0), tol=tol * 4, what="fused column sums, accumulated")
     # weight gradient (split-K)
     dw = torch.zeros(N, Kd, device=DEV)
     close(K.linear_bwd_weight_pl(dyp, xp, dw), dy.T @ x, tol=tol, what="wgrad")
