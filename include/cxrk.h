@@ -168,9 +168,8 @@ int cxrk_residual_ln_bwd(const float* dy, const float* xhat, const float* rstd, 
 int cxrk_planes_add_rows(const void* src, long plane, long rows, int cols, float* dst, long ld, hipStream_t stream);
 int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, int nH, int dH, void* ctx, long ctxplane, float* probs,
                   hipStream_t stream);
-/* colpart (optional, [B][3*nH*dH] fp32): per-sequence column sums of dq | dk | dv — summed over B they are the q/k/v bias gradients */
 int cxrk_attn_bwd(const float* qkv, const float* probs, const float* dctx, int B, int L, int nH, int dH, void* dqkv,
-                  long dqkvplane, float* colpart, hipStream_t stream);
+                  long dqkvplane, hipStream_t stream);
 int cxrk_embed_bwd(const long* ids, const float* dx, long T, int H, float* dword, hipStream_t stream);
 /* dx = dy * gelu'(pre): the erf-GELU between dense_to_hidden and LayerNorm of BertProjectionHead (modelling_cxrbert.py:45-46). */
 int cxrk_gelu_bwd(const float* dy, const float* pre, long n, float* dx, hipStream_t stream);

@@ -371,8 +371,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 // dV = P^T dO ; dP = dO V^T ; dS = P o (dP - rowsum(dP o P)) ; dQ = scale * dS K ; dK = scale * dS^T Q
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
                                                        const float* __restrict__ dctx, int L, int nH, int dH, float scale,
-                                                       float* __restrict__ dqkv, unsigned short* __restrict__ dqkvp, long dqkvplane,
-                                                       float* __restrict__ colpart) {
+                                                       float* __restrict__ dqkv, unsigned short* __restrict__ dqkvp, long dqkvplane) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int ALD = dH + 4;
   float* Qs = smem; float* Ks = Qs + L * ALD; float* Vs = Ks + L * ALD; float* Os = Vs + L * ALD;
@@ -419,9 +418,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     if (dqkvp) { const float t[4] = {v.x, v.y, v.z, v.w}; planes_store4(dqkvp, dqkvplane, qbase + off, t); }
     else *reinterpret_cast<float4*>(dq + off) = v;
   };
-  // colpart (optional): [B][3*nH*dH] column sums of this sequence's dq | dk | dv rows = its share of the q/k/v bias gradients,
-  // so that no pass over the [T][3H] gradient is needed for them (256 % (dH/4) == 0: a thread keeps one column group)
-  float4 sq = make_float4(0.f, 0.f, 0.f, 0.f), sk = sq, sv = sq;
   for (int blk = threadIdx.x; blk < nb * d4; blk += 256) {
     const int i0 = 2 * (blk / d4), c = blk % d4;
     const int i1 = min(i0 + 1, L - 1);
@@ -437,28 +433,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     }
     const long o0 = (long)i0 * ld + c * 4;
     put(o0, q0); put(o0 + nH * dH, k0); put(o0 + 2 * nH * dH, v0);
-    sq.x += q0.x; sq.y += q0.y; sq.z += q0.z; sq.w += q0.w; sk.x += k0.x; sk.y += k0.y; sk.z += k0.z; sk.w += k0.w;
-    sv.x += v0.x; sv.y += v0.y; sv.z += v0.z; sv.w += v0.w;
     if (i0 + 1 < L) {
       const long o1 = (long)i1 * ld + c * 4;
       put(o1, q1); put(o1 + nH * dH, k1); put(o1 + 2 * nH * dH, v1);
-      sq.x += q1.x; sq.y += q1.y; sq.z += q1.z; sq.w += q1.w; sk.x += k1.x; sk.y += k1.y; sk.z += k1.z; sk.w += k1.w;
-      sv.x += v1.x; sv.y += v1.y; sv.z += v1.z; sv.w += v1.w;
-    }
-  }
-  if (colpart) {   // wave-uniform
-    __syncthreads();                       // every thread is done with Q/K/V/dO in LDS: reuse them as [256 / d4][3][dH]
-    const int rp = threadIdx.x / d4, c = threadIdx.x % d4, nrp = 256 / d4;
-    float* red = smem;
-    *reinterpret_cast<float4*>(red + (rp * 3 + 0) * dH + c * 4) = sq;
-    *reinterpret_cast<float4*>(red + (rp * 3 + 1) * dH + c * 4) = sk;
-    *reinterpret_cast<float4*>(red + (rp * 3 + 2) * dH + c * 4) = sv;
-    __syncthreads();
-    for (int t = threadIdx.x; t < 3 * dH; t += 256) {
-      const int which = t / dH, col = t - which * dH;
-      float a = 0.f;
-      for (int r_ = 0; r_ < nrp; ++r_) a += red[(r_ * 3 + which) * dH + col];   // fixed order
-      colpart[(long)b * (3 * nH * dH) + which * (nH * dH) + hd * dH + col] = a;
     }
   }
 }
@@ -601,17 +578,14 @@ extern "C" int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, i
 }
 
 extern "C" int cxrk_attn_bwd(const float* qkv, const float* probs, const float* dctx, int B, int L, int nH, int dH,
-                             void* dqkvv, long dqkvplane, float* colpart, hipStream_t stream) {
+                             void* dqkvv, long dqkvplane, hipStream_t stream) {
   CXRK_CHECK_ARG(qkv && probs && dctx && dqkvv && B > 0 && nH > 0 && aligned16(qkv) && aligned16(dctx) && aligned16(dqkvv) && dqkvplane >= 0 &&
                  (dqkvplane % 4) == 0);
   float* dqkv = dqkvplane ? nullptr : static_cast<float*>(dqkvv);
   unsigned short* dqkvp = dqkvplane ? static_cast<unsigned short*>(dqkvv) : nullptr;
   if (dH > AD || dH < 4 || (dH % 4) != 0 || L > AL || L < 1) return CXRK_ERR_UNSUPPORTED;
-  if (colpart && 256 % (dH / 4) != 0) return CXRK_ERR_UNSUPPORTED;
   const int ALD = dH + 4;
-  size_t sh = (size_t)(4 * L * ALD + 2 * L * (L + 1)) * sizeof(float);
-  const size_t red = colpart ? (size_t)(256 / (dH / 4)) * 3 * dH * sizeof(float) : 0;   // reduction area: reuses the whole buffer
-  if (red > sh) sh = red;
+  const size_t sh = (size_t)(4 * L * ALD + 2 * L * (L + 1)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -619,7 +593,7 @@ extern "C" int cxrk_attn_bwd(const float* qkv, const float* probs, const float* 
     attr_set = true;
   }
   hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * nH)), dim3(256), sh, stream, qkv, probs, dctx, L, nH, dH,
-                     1.0f / sqrtf((float)dH), dqkv, dqkvp, dqkvplane, colpart);
+                     1.0f / sqrtf((float)dH), dqkv, dqkvp, dqkvplane);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
 }

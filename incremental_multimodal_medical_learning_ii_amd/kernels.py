@@ -727,16 +727,11 @@ def attn_fwd(qkv, mask, B, L, nH, dH, save_probs: bool = True, out_planes: bool 
     return ctx, probs
 
 
-def attn_bwd(qkv, probs, dctx, B, L, nH, dH, out_planes: bool = False, bias_grad=None, bias_accumulate: bool = False):
-    """dqkv [T, 3H] (fp32 or planes).  `bias_grad` ([3H], optional) receives (accumulates) the column sums of dqkv — the fused q/k/v
-    bias gradient — from per-sequence partial sums the kernel writes beside dqkv (no second pass over the [T, 3H] tensor)."""
+def attn_bwd(qkv, probs, dctx, B, L, nH, dH, out_planes: bool = False):
     lib = _lib.load()
     dqkv, dp, dpl = _new_out(qkv.shape[0], qkv.shape[1], qkv.device, out_planes)
-    part = torch.empty(B, 3 * nH * dH, dtype=torch.float32, device=qkv.device) if bias_grad is not None else None
-    check(lib.cxrk_attn_bwd(_p(qkv), _p(probs), _p(_chk(dctx, "attn.dctx")), B, L, nH, dH, dp, dpl, _p(part), _stream()),
+    check(lib.cxrk_attn_bwd(_p(qkv), _p(probs), _p(_chk(dctx, "attn.dctx")), B, L, nH, dH, dp, dpl, _stream()),
           "cxrk_attn_bwd")
-    if part is not None:
-        colsum(part, bias_grad, accumulate=bias_accumulate)
     return dqkv
 
 

@@ -266,20 +266,20 @@ def _backward(p: Sequence[torch.Tensor], ids: torch.Tensor, n_layers: int, n_hea
         else:
             wb(dt1, s.ctx, o + 6, bias=False)
             dctx = _dgrad(dt1, wo_w, pl)
-        # fused q/k/v gradients: one [3H, H] GEMM into the three (adjacent) .grad slices when they are adjacent too; the bias
-        # gradient (column sums of dqkv) comes out of the attention backward as per-sequence partial sums
+        dqkv = K.attn_bwd(s.qkv, s.probs, dctx, N, L, n_heads, H // n_heads, out_planes=pl)
+        # fused q/k/v gradients: one [3H, H] GEMM into the three (adjacent) .grad slices when they are adjacent too
         gq = [getattr(sink.params[o + j], "grad", None) for j in (0, 2, 4)]
         gb = [getattr(sink.params[o + j], "grad", None) for j in (1, 3, 5)]
         gw_f = _fused(*gq) if all(t is not None and t.dtype == torch.float32 for t in gq) else None
         gb_f = _fused(*gb) if all(t is not None and t.dtype == torch.float32 for t in gb) else None
         if gw_f is not None and gb_f is not None:
-            dqkv = K.attn_bwd(s.qkv, s.probs, dctx, N, L, n_heads, H // n_heads, out_planes=pl, bias_grad=gb_f, bias_accumulate=True)
             _wgrad(dqkv, s.x, gw_f, True, pl)
+            K.colsum(dqkv, gb_f, accumulate=True)
         else:
             dwqkv = torch.empty(3 * H, H, dtype=torch.float32, device=dev)
             dbqkv = torch.empty(3 * H, dtype=torch.float32, device=dev)
-            dqkv = K.attn_bwd(s.qkv, s.probs, dctx, N, L, n_heads, H // n_heads, out_planes=pl, bias_grad=dbqkv)
             _wgrad(dqkv, s.x, dwqkv, False, pl)
+            K.colsum(dqkv, dbqkv)
             for j in range(3):
                 sink.ret[o + 2 * j], sink.ret[o + 2 * j + 1] = dwqkv[j * H:(j + 1) * H], dbqkv[j * H:(j + 1) * H]
         if rows_cls:   # the residual branch x -> t1 exists for the CLS rows only
