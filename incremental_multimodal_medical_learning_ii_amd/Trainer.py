@@ -671,21 +671,23 @@ class Trainer:
     # ------------------------------------------------------------------------------------------------ checkpoint
     @torch.no_grad()
     def save(self):
-        """`Trainer.py:1643-1648`: whole-module `torch.save` into the writer's log dir (same file names)."""
+        """`Trainer.py:1643-1648`: the adapters into the writer's log dir under the reference's file names.  The reference pickles
+        the whole module; here the file holds the module's state dict (tensors only), so that `load` — like every other loader of
+        this package — can run with `weights_only=True`."""
         if self._has_img:
-            torch.save(self.image_adapter, os.path.join(self.writer.log_dir, 'image_adapter.pt'))
+            torch.save(self.image_adapter.state_dict(), os.path.join(self.writer.log_dir, 'image_adapter.pt'))
         if self._has_txt:
-            torch.save(self.text_adapter, os.path.join(self.writer.log_dir, 'text_adapter.pt'))
+            torch.save(self.text_adapter.state_dict(), os.path.join(self.writer.log_dir, 'text_adapter.pt'))
         if hasattr(self.writer, "flush"):
             self.writer.flush()
 
     @torch.no_grad()
     def load(self):
-        """Counterpart of `save` (the reference's `load`, `Trainer.py:1650-1655`, mistakenly calls `torch.save` for
-        the text adapter).  Only files this class wrote are expected here."""
-        if self._has_img:
-            sd = torch.load(os.path.join(self.writer.log_dir, 'image_adapter.pt'), weights_only=False).state_dict()
-            self.image_adapter.load_state_dict(sd)
-        if self._has_txt:
-            sd = torch.load(os.path.join(self.writer.log_dir, 'text_adapter.pt'), weights_only=False).state_dict()
-            self.text_adapter.load_state_dict(sd)
+        """Counterpart of `save` (the reference's `load`, `Trainer.py:1650-1655`, mistakenly calls `torch.save` for the text
+        adapter).  Files are opened with `weights_only=True`: a pickled module, as the reference writes, is refused."""
+        for has, mod, name in ((self._has_img, self.image_adapter, 'image_adapter.pt'), (self._has_txt, self.text_adapter, 'text_adapter.pt')):
+            if has:
+                sd = torch.load(os.path.join(self.writer.log_dir, name), map_location="cpu", weights_only=True)
+                if not isinstance(sd, dict):
+                    raise ValueError(f"{name}: expected a state dict of tensors")
+                mod.load_state_dict(sd)
