@@ -47,6 +47,18 @@ def adapter_logits(img_ad, txt_ad, embs, bert_out, n_cols: Optional[int] = None,
     return ref_loss.posneg_logits(x, pos, neg, diff)
 
 
+def adapter_logits_max_emb(img_ad, txt_ad, embs, bert_out, diff: bool = True):
+    """The same logits with `MAX_EMB` (`Trainer.py:1664-1666,1691-1693`): the prompt embeddings of a class are NOT averaged; the
+    cosine against each prompt is taken and the maximum over the class's prompts is the class's (positive / negative) score."""
+    x = mlp_adapter(img_ad, embs) if img_ad is not None else embs
+    g, n, d = bert_out.shape
+    e = bert_out.reshape(g * n, d)
+    if txt_ad is not None:
+        e = mlp_adapter(txt_ad, e)
+    mx, _, _ = ref_loss.pairwise_cosine_max(x, e, g)          # [B, 2C]
+    return (mx[:, 0::2] - mx[:, 1::2]) if diff else mx[:, 0::2]
+
+
 def adapter_step(img_ad: Dict[str, torch.Tensor], txt_ad: Dict[str, torch.Tensor], embs, labels, bert_out,
                  optimizer: torch.optim.Optimizer, n_cols: Optional[int] = None):
     """One reference train step.  Parameters in the dicts must be leaf tensors owned by `optimizer`."""

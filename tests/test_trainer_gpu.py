@@ -77,6 +77,46 @@ def test_joint_train_val_test_match_oracle(tmp_path):
     assert abs(tr2.writer.scalars("train/Loss")[0][1] - float(ref)) / float(ref) < 1e-5
 
 
+def test_max_emb_training_step_matches_oracle(tmp_path, monkeypatch):
+    """`MAX_EMB = True` (`Trainer.py:43,1691-1703`): scores are the maximum cosine over a class's prompts.  One training step of the
+    fused path (`cxrk_pairwise_cosine_max_fwd/bwd` + BCE) and of the reference's per-class `myCosineSimilarity` path against the
+    oracle: loss, both adapters after the Adam step, and the logged max-vs-mean gaps."""
+    monkeypatch.setattr(TR, "MAX_EMB", True)
+    tr, classes, prompts = _trainer(tmp_path)
+    ip, tp, bert_out = _oracle_state(tr, classes, prompts)
+    opt = torch.optim.Adam(list(tp.values()) + list(ip.values()), lr=1e-3)
+    train, _, _ = TR.Trainer.synthetic_loaders(96, 8, 8, batch_size=96, shuffle=False)
+    e, l = next(iter(train))
+    crit = nn.BCEWithLogitsLoss()
+    tr.train([(e, l)], crit, epoch=1)
+    opt.zero_grad()
+    logits = ref_step.adapter_logits_max_emb(ip, tp, e, bert_out)
+    ref = nn.functional.binary_cross_entropy_with_logits(logits, l)
+    ref.backward()
+    opt.step()
+    got = tr.writer.scalars("train/Loss")[0][1]
+    assert abs(got - float(ref)) < 1e-5, (got, float(ref))
+    for k, v in tr.image_adapter.state_dict().items():
+        assert float((v.cpu() - ip[k].detach()).abs().max() / ip[k].detach().abs().max()) < 1e-4, k
+    for k, v in tr.text_adapter.state_dict().items():
+        assert float((v.cpu() - tp[k].detach()).abs().max() / tp[k].detach().abs().max()) < 1e-4, k
+    gaps = [v for _, v, _ in tr.writer.scalars("max-mean-comparison/pos")]
+    assert len(gaps) == len(classes) and all(g >= 0 for g in gaps)      # max >= mean, one log entry per class as in the reference
+    # the reference's own per-call form (myCosineSimilarity on one class's un-averaged prompt set) gives the same numbers
+    with torch.no_grad():
+        x = tr.image_adapter(e.to(DEV))
+        pe, ne = tr.bert_forward_mean(prompts[classes[0]]["positive"], prompts[classes[0]]["negative"], use_grad=False)
+        assert pe.shape[0] == len(prompts[classes[0]]["positive"])      # not averaged under MAX_EMB
+        ps = tr.myCosineSimilarity(x, pe, use_grad=False)
+        full = ref_loss_cos(x.cpu(), pe.cpu()).max(dim=1).values
+        assert float((ps.cpu() - full).abs().max()) < 1e-5
+
+
+def ref_loss_cos(x, y):
+    from oracle import ref_loss
+    return ref_loss.pairwise_cosine_similarity(x, y)
+
+
 def test_class_incremental_and_weight_reset(tmp_path):
     tr, classes, prompts = _trainer(tmp_path)
     ip, tp, bert_out = _oracle_state(tr, classes, prompts)
