@@ -483,8 +483,8 @@ def test_epilogue_lane_maps_standalone():
     guard regions around all buffers (a store outside its tensor is reported, not a fault) against a CPU fp64 reference."""
     import subprocess
     exe = os.path.join(os.path.dirname(_cxr_lib.__file__), "csrc", "epilogue_check")
-    if not os.path.exists(exe):
-        pytest.fail("csrc/epilogue_check is not built (make -C incremental_multimodal_medical_learning_ii_amd/csrc)")
+    if not os.path.exists(exe):   # normally built by __graft_entry__.build() with the library; the box has hipcc too
+        subprocess.run(["make", "-C", os.path.dirname(exe), "epilogue_check"], check=True, timeout=600)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     bad = [ln for ln in r.stdout.splitlines() if ln.startswith("FAIL")]
     assert r.returncode == 0 and not bad and "0 failing cases" in r.stdout, "\n".join(bad[:10]) + r.stderr[-500:]
