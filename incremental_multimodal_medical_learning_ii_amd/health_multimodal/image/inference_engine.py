@@ -15,42 +15,47 @@ TypeShape2D = Tuple[int, int]
 
 
 class ImageInferenceEngine:
-    """Inference-time operations on an image model."""
+    """Image side of the zero-shot pipeline: file -> transform -> `ImageModel` -> L2-normalised embedding(s)."""
 
     def __init__(self, image_model: ImageModel, transform: Compose):
-        assert isinstance(image_model, ImageModel), f"Expected an ImageModel, got {type(image_model)}"
-        self.model = image_model
+        if not isinstance(image_model, ImageModel):
+            raise AssertionError(f"Expected an ImageModel, got {type(image_model)}")
+        self.model = image_model.eval()
         self.transform = transform
-        self.model.eval()
-        self.resize_size, self.crop_size = infer_resize_params(self.transform.transforms)
         self.to = self.model.to
+        # what the transform pipeline does to the image geometry; the similarity-map code undoes it (vlp/inference_engine.py)
+        self.resize_size, self.crop_size = infer_resize_params(transform.transforms)
+
+    def _device(self) -> torch.device:
+        return next(self.model.parameters()).device
 
     def load_and_transform_input_image(self, image_path: Path, transform: Callable) -> Tuple[torch.Tensor, TypeShape2D]:
-        """Read an image, apply the transform, add the batch dimension, move to the model's device."""
+        """-> (a [1, C, H, W] batch on the model's device, the (width, height) the file had before the transform)."""
         image = load_image(image_path)
-        size = tuple(image.size) if hasattr(image, "size") and not isinstance(image, torch.Tensor) else tuple(image.shape[-2:][::-1])
-        device = next(self.model.parameters()).device
-        transformed_image = transform(image).unsqueeze(0).to(device)
-        return transformed_image, size
+        if isinstance(image, torch.Tensor):
+            original = (int(image.shape[-1]), int(image.shape[-2]))
+        else:
+            original = tuple(image.size)
+        batch = transform(image)[None].to(self._device())
+        return batch, original
 
     @torch.no_grad()
     def get_projected_patch_embeddings(self, image_path: Path) -> Tuple[torch.Tensor, TypeShape2D]:
-        """L2-normalised patch embeddings [h, w, feature_size] and the original (width, height)."""
-        input_image, img_shape = self.load_and_transform_input_image(image_path, self.transform)
-        projected_img_emb = self.model.get_patchwise_projected_embeddings(input_image, normalize=True)
-        assert projected_img_emb.shape[0] == 1
-        return projected_img_emb[0], img_shape
+        """Grid of L2-normalised patch embeddings [h, w, joint_feature_dim] of one image, and its original (width, height)."""
+        batch, original = self.load_and_transform_input_image(image_path, self.transform)
+        grid = self.model.get_patchwise_projected_embeddings(batch, normalize=True)
+        assert grid.shape[0] == 1
+        return grid[0], original
 
     @torch.no_grad()
     def get_projected_global_embedding(self, image_path: Path) -> torch.Tensor:
-        """L2-normalised global image embedding [joint_feature_dim]."""
-        input_image, _ = self.load_and_transform_input_image(image_path, self.transform)
-        return self.get_projected_global_embedding_from_tensor(input_image)[0]
+        """L2-normalised global embedding [joint_feature_dim] of one image."""
+        batch, _ = self.load_and_transform_input_image(image_path, self.transform)
+        return self.get_projected_global_embedding_from_tensor(batch)[0]
 
     @torch.no_grad()
     def get_projected_global_embedding_from_tensor(self, images: torch.Tensor) -> torch.Tensor:
-        """Batched form: images [B,3,H,W] on the model's device -> L2-normalised [B, joint_feature_dim]."""
+        """Batched form used by the zero-shot evaluation: [B, 3, H, W] on the model's device -> L2-normalised [B, joint_feature_dim]."""
         emb = self.model.forward(images)
         assert emb.ndim == 2
-        xhat, _ = K.l2norm_fwd(emb)
-        return xhat
+        return K.l2norm_fwd(emb)[0]
