@@ -161,6 +161,7 @@ def test_class_incremental_and_weight_reset(tmp_path):
 
 def test_data_incremental_schedule_runs(tmp_path):
     """DATA_INCREMENTAL.py:75-90 shape: 5 contiguous shards, epochs per shard, val + test after each."""
+    torch.manual_seed(27)   # the shard loaders draw their batches with RandomSampler, like the reference's (Trainer.py:1214-1231)
     tr, classes, prompts = _trainer(tmp_path)
     train, val, test = TR.Trainer.synthetic_loaders(320, 64, 64, batch_size=32, shuffle=False)
     parts = TR.Trainer.split_dataloader_data_incremental(train, 5)
@@ -168,6 +169,7 @@ def test_data_incremental_schedule_runs(tmp_path):
     for part, loader in enumerate(parts, start=1):
         tr.train(loader, crit, epoch=1, part=part, epochs=1)
     losses = [v for _, v, _ in tr.writer.scalars("train/Loss")]
-    assert len(losses) == 10 and losses[-1] < losses[0]
+    # every batch is new data (5 disjoint shards x 2 batches), so single losses fluctuate: compare halves, not end points
+    assert len(losses) == 10 and sum(losses[5:]) < sum(losses[:5])
     steps = [s for _, _, s in tr.writer.scalars("train/Loss")]
     assert steps == list(range(1, 11))
