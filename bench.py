@@ -305,18 +305,23 @@ def main():
         probe_names = ("encoder.encoder.layer4.2.conv3.weight", "encoder.encoder.layer1.0.conv1.weight")
         tprobe = "bert.encoder.layer.11.intermediate.dense.weight"
         inamed, tnamed = dict(trainer.image_model.named_parameters()), dict(trainer.text_model.named_parameters())
-        for mode in ("fp32", "split_bf16"):
-            cxr_lib.set_precision(mode)
+        # third leg: exact fp32 again, with the images scaled by (1 + 1e-6): how far the image-encoder gradients move when the
+        # forward changes in the last bits only — the conditioning against which the split-bf16 gradient differences must be read
+        jitter = images * (1.0 + 1e-6)
+        for mode in ("fp32", "fp32_jitter", "split_bf16"):
+            cxr_lib.set_precision("split_bf16" if mode == "split_bf16" else "fp32")
             trainer.optimizer.zero_grad()
-            ls = trainer.forward_loss(images, ids, mask)
+            src = jitter if mode == "fp32_jitter" else images
+            ls = trainer.forward_loss(src, ids, mask)
             ls.backward()
             with torch.no_grad():
-                ie = trainer.image_model(images[:64]).clone()
+                ie = trainer.image_model(src[:64]).clone()
                 te = trainer.text_model.get_projected_text_embeddings(ids[:64], mask[:64], normalize_embeddings=False).clone()
             vals[mode] = (ie, te, ls.detach().clone(), [inamed[n].grad.detach().clone() for n in probe_names], tnamed[tprobe].grad.detach().clone())
+        del jitter
         trainer.optimizer.zero_grad()
         cxr_lib.set_precision(args.precision)
-        a, b = vals["fp32"], vals["split_bf16"]
+        a, b, j = vals["fp32"], vals["split_bf16"], vals["fp32_jitter"]
         rel = lambda x, y: float(((x - y).abs().max() / y.abs().max().clamp_min(1e-30)).item())
         nrel = lambda x, y: float(((x - y).norm() / y.norm().clamp_min(1e-30)).item())
         precision_check = {"what": "bench batch and weights through forward + backward in split_bf16 vs exact fp32 contractions "
@@ -324,7 +329,13 @@ def main():
                            "image_embedding": rel(b[0], a[0]), "text_embedding": rel(b[1], a[1]),
                            "loss": abs(float(b[2]) - float(a[2])) / abs(float(a[2])),
                            "grad_image_layer4_conv3": nrel(b[3][0], a[3][0]), "grad_image_layer1_conv1": nrel(b[3][1], a[3][1]),
-                           "grad_text_layer11_ffn": nrel(b[4], a[4]), "bar": 1e-3}
+                           "grad_text_layer11_ffn": nrel(b[4], a[4]), "bar": 1e-3,
+                           "fp32_vs_fp32_with_inputs_scaled_by_1p000001": {
+                               "image_embedding": rel(j[0], a[0]), "grad_image_layer4_conv3": nrel(j[3][0], a[3][0]),
+                               "grad_image_layer1_conv1": nrel(j[3][1], a[3][1]),
+                               "note": "exact-fp32 against exact-fp32 on images * (1 + 1e-6): the image-encoder gradients move by this "
+                                       "much when the forward changes in the last bits (ReLU / max-pool decisions on the other side of "
+                                       "zero, DESIGN.md section 2); the split_bf16 rows above are to be read against it, not against `bar`"}}
         del vals
         log(f"precision check: {precision_check}")
 
