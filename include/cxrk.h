@@ -149,7 +149,7 @@ int cxrk_spatial_mean_bwd_pl(const float* dy, const float* add, void* dx, long d
  *              xhat, rstd saved for bwd; bwd: dx = LN'(dy) + dx_add, dgamma/dbeta reduced deterministically.
  * attn:        ctx = softmax(Q K^T / sqrt(d) + keymask) V per (sequence, head); qkv is the fused [T][3*nH*d]
  *              projection output; probs [B][nH][L][L] saved for bwd.  L <= 64, d <= 64 (multiple of 4).
- * embed_bwd:   dword[ids[t]] += dx[t]   (fp32 atomics)
+ * embed_bwd:   dword[ids[t]] += dx[t], summed in token order per row (sort by (id, position) + segmented sums: deterministic, no atomics)
  * Outputs declared `void* y, long yplane`: yplane = 0 -> fp32 tensor; yplane > 0 -> planes (bf16 hi at y, lo at y + yplane
  * elements), the format the following GEMM consumes in split-bf16 mode.
  */
@@ -170,7 +170,8 @@ int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, int nH, int 
                   hipStream_t stream);
 int cxrk_attn_bwd(const float* qkv, const float* probs, const float* dctx, int B, int L, int nH, int dH, void* dqkv,
                   long dqkvplane, hipStream_t stream);
-int cxrk_embed_bwd(const long* ids, const float* dx, long T, int H, float* dword, hipStream_t stream);
+size_t cxrk_embed_bwd_ws_bytes(long T, int H);
+int cxrk_embed_bwd(const long* ids, const float* dx, long T, int H, float* dword, float* ws, size_t ws_bytes, hipStream_t stream);
 /* dx = dy * gelu'(pre): the erf-GELU between dense_to_hidden and LayerNorm of BertProjectionHead (modelling_cxrbert.py:45-46). */
 int cxrk_gelu_bwd(const float* dy, const float* pre, long n, float* dx, hipStream_t stream);
 

@@ -52,7 +52,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_planes_add_rows": (I, [P, L, L, I, P, L, P]),
     "cxrk_attn_fwd": (I, [P, P, I, I, I, I, P, L, P, P]),
     "cxrk_attn_bwd": (I, [P, P, P, I, I, I, I, P, L, P]),
-    "cxrk_embed_bwd": (I, [P, P, L, I, P, P]),
+    "cxrk_embed_bwd_ws_bytes": (Z, [L, I]),
+    "cxrk_embed_bwd": (I, [P, P, L, I, P, P, Z, P]),
     "cxrk_gelu_bwd": (I, [P, P, L, P, P]),
     "cxrk_l2norm_fwd": (I, [P, L, I, F, P, L, P, P]),
     "cxrk_l2norm_bwd": (I, [P, P, L, P, L, I, P, P]),

@@ -440,14 +440,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   }
 }
 
-// dword[ids[t]] += dx[t]  (fp32 atomics: 256 contiguous bytes per wave-instruction; MI355X_MICROARCH "Global float atomics")
-__global__ void embed_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ dx, long T, int H,
-                                 float* __restrict__ dword) {
-  const long t = blockIdx.x;
-  float* dst = dword + ids[t] * H;
-  for (int c = threadIdx.x; c < H; c += blockDim.x) atomicAdd(dst + c, dx[t * H + c]);
-}
-
 // dst[r*ld + c] += src[r][c]  (src planes [rows][cols], cols % 8 == 0): adds a small planes tensor into strided rows of an fp32 one
 // (the CLS rows of a [N, L, H] gradient)
 __global__ void planes_add_rows_kernel(const unsigned short* __restrict__ src, long plane, long rows, int cols, float* __restrict__ dst,
@@ -598,9 +590,3 @@ extern "C" int cxrk_attn_bwd(const float* qkv, const float* probs, const float* 
   return CXRK_OK;
 }
 
-extern "C" int cxrk_embed_bwd(const long* ids, const float* dx, long T, int H, float* dword, hipStream_t stream) {
-  CXRK_CHECK_ARG(ids && dx && dword && T > 0 && H > 0);
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)T), dim3(256), 0, stream, ids, dx, T, H, dword);
-  CXRK_LAUNCH_CHECK();
-  return CXRK_OK;
-}

@@ -747,9 +747,12 @@ def planes_add_rows(src: Planes, dst: torch.Tensor) -> torch.Tensor:
 
 
 def embed_bwd(ids, dx, dword):
+    """dword[ids[t]] += dx[t]; every row is summed in ascending token position (deterministic: csrc/embed.hip)."""
     lib = _lib.load()
     T, H = dx.shape
-    check(lib.cxrk_embed_bwd(_p(ids), _p(_chk(dx, "embed.dx")), T, H, _p(dword), _stream()), "cxrk_embed_bwd")
+    ws = workspace(lib.cxrk_embed_bwd_ws_bytes(T, H), dx.device)
+    check(lib.cxrk_embed_bwd(_p(ids), _p(_chk(dx.contiguous(), "embed.dx")), T, H, _p(dword), _p(ws), ws.numel() * 4, _stream()),
+          "cxrk_embed_bwd")
 
 
 def gelu_bwd(dy, pre):

@@ -434,6 +434,22 @@ def test_embed_ln_and_scatter():
     K.embed_bwd(ids.to(DEV).view(-1), dx.to(DEV), dword)
     refw = torch.zeros(V, H).index_add_(0, ids.view(-1), dx)
     close(dword, refw, what="embed scatter-add")
+    # token-id statistics of a real batch: a few ids ([PAD], [CLS], [SEP]) own long runs that span many 32-entry chunks of the sorted
+    # list, most ids occur once or twice; T not a multiple of the chunk; accumulation into a non-zero buffer; two runs bit-identical
+    g = torch.Generator().manual_seed(11)
+    T, V2, H2 = 4099, 300, 72
+    ids2 = torch.randint(0, V2, (T,), generator=g)
+    ids2[torch.rand(T, generator=g) < 0.55] = 0          # "[PAD]"
+    ids2[::32] = 101 % V2                                 # "[CLS]" at a fixed stride
+    ids2[-7:] = V2 - 1                                    # a run that ends the sorted list
+    dx2 = rnd(T, H2, seed=12)
+    base = rnd(V2, H2, seed=13)
+    out1, out2 = base.clone().to(DEV), base.clone().to(DEV)
+    K.embed_bwd(ids2.to(DEV), dx2.to(DEV), out1)
+    K.embed_bwd(ids2.to(DEV), dx2.to(DEV), out2)
+    ref2 = base.double().index_add_(0, ids2, dx2.double()).float()
+    close(out1, ref2, what="embed scatter-add, long runs")
+    assert torch.equal(out1, out2), "the scatter must be deterministic (no atomics)"
 
 
 @pytest.mark.parametrize("L,ragged", [(32, False), (32, True), (17, True), (64, False), (16, "empty")])
