@@ -156,3 +156,20 @@ def test_flat_optimizer_layout_is_independent_of_allocation_addresses():
     off = {n: (p.data_ptr() - base) // 4 for n, p in (("a", a), ("q", q), ("k", k), ("v", v), ("c", c))}
     assert off == {"a": 0, "q": 8, "k": 16, "v": 24, "c": 32}, off
     assert torch.equal(opt.flat_p[8:32], torch.arange(24, dtype=torch.float32))   # q|k|v still one contiguous block
+
+
+def test_gradient_span_of_a_parameter_subset():
+    """`optim.grad_span`: the element range of the flat gradient buffer that holds exactly a subset's gradients — what the
+    data-parallel step all-reduces early for the text encoder — or None when the subset is not one gap-free range."""
+    import torch
+    from incremental_multimodal_medical_learning_ii_amd import optim as cxr_optim
+    img = [torch.nn.Parameter(torch.zeros(10)), torch.nn.Parameter(torch.zeros(3, 5))]      # padded to 12 + 16 elements
+    fused = torch.zeros(24)
+    txt = [torch.nn.Parameter(fused[8:16]), torch.nn.Parameter(fused[0:8]), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(fused[16:24])]
+    opt = cxr_optim.SGD(img + txt, lr=0.1)
+    assert opt.grad_span(txt) == (28, 28 + 24 + 8)          # the shared storage stays together, then the 7-element tensor (padded to 8)
+    assert opt.grad_span(img) == (0, 28)
+    assert opt.grad_span([img[0], txt[2]]) is None           # not contiguous: the caller falls back to one all-reduce of everything
+    assert opt.grad_span([]) is None
+    lo, hi = opt.grad_span(txt)
+    assert hi == opt.flat_g.numel() and all(lo <= (p.grad.data_ptr() - opt.flat_g.data_ptr()) // 4 < hi for p in txt)
