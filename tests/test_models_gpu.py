@@ -382,8 +382,8 @@ def test_joint_step_two_streams_equals_one_stream():
 
 # ------------------------------------------------------------------------------------------------ BASELINE config 1
 def test_zero_shot_engine_config1():
-    """ZERO_JOINT_BOUNDS-style zero-shot (BASELINE.json configs[0], scaled to 8 images): synthetic 224x224 images x 5
-    CheXpert class prompt sets through ImageTextInferenceEngine vs the CPU oracle (trash/lower_bound_mcs.py:79-117)."""
+    """ZERO_JOINT_BOUNDS-style zero-shot at BASELINE.json configs[0]'s size: 64 synthetic 224x224 images x 5 CheXpert class prompt
+    sets through ImageTextInferenceEngine vs the CPU oracle (trash/lower_bound_mcs.py:79-117)."""
     from incremental_multimodal_medical_learning_ii_amd.DataRetrieval import CHEXPERT_COMPETITION_CLASSES, create_prompts
     from incremental_multimodal_medical_learning_ii_amd.health_multimodal.image import ImageInferenceEngine
     from incremental_multimodal_medical_learning_ii_amd.health_multimodal.image.data.transforms import create_chest_xray_transform_for_inference
@@ -402,9 +402,9 @@ def test_zero_shot_engine_config1():
                                    TextInferenceEngine(tok, tm.to(DEV)))
     classes = list(CHEXPERT_COMPETITION_CLASSES)
     prompts = create_prompts(classes)
-    images = syn.synthetic_images(8, 224, seed=5)
+    images = syn.synthetic_images(64, 224, seed=5)
     scores = eng.get_similarity_scores_from_tensors(images.to(DEV), [prompts[c]["positive"] for c in classes])
-    assert scores.shape == (8, 5)
+    assert scores.shape == (64, 5)
     img_ref = ref_image.image_model_forward(isd, images)
     txt_ref = []
     for c in classes:
@@ -412,7 +412,9 @@ def test_zero_shot_engine_config1():
         txt_ref.append(ref_text.cxrbert_projected(tsd, t.input_ids, t.attention_mask, 2, 2).mean(0))
     ref = ref_loss.zero_shot_scores(img_ref, torch.stack(txt_ref))
     assert rel(scores, ref) < TOL, rel(scores, ref)
-    assert torch.equal(scores.argmax(1).cpu(), ref.argmax(1))
+    top2 = ref.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4            # the predicted class, wherever the oracle's own margin is not a rounding tie
+    assert bool(clear.any()) and torch.equal(scores.argmax(1).cpu()[clear], ref.argmax(1)[clear])
     # single-image API through a file (vlp/inference_engine.py:31-57)
     import numpy as np, tempfile, os
     with tempfile.TemporaryDirectory() as d:
