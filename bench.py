@@ -14,7 +14,14 @@ exact fp32 MFMA, measured beside it as `other_precision`).  Synthetic data resid
 seeded random-init weights.
 The two encoders run on two HIP streams (contrastive.JointContrastiveTrainer); the per-kernel profile behind `roofline` is
 taken over two extra single-stream steps after the timed region (see the comment there), `precision_check` compares the
-split-bf16 forward with the exact-fp32 one on the bench batch.
+split-bf16 forward and backward with the exact-fp32 ones on the bench batch (free-running, and with the fp32 forward's ReLU /
+max-pool decisions imposed on the split-bf16 backward).
+The timed steps train a model with LIVE gradients: BatchNorm statistics are calibrated on a sample batch (synthetic weights then
+map different images to different embeddings, like a trained checkpoint), the learning rate keeps the 133 M-parameter model in the
+first, descending phase of contrastive training for the whole run, and the line carries the loss trace, the norm of the loss
+gradient w.r.t. the embeddings before and after the timed region (`cotangent_norm`) and per-step times (`step_ms`); the run
+refuses to print a number measured on collapsed embeddings (cotangents fallen to < 10 % of their initial norm, or all embeddings
+parallel).
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
 from __future__ import annotations
@@ -33,6 +40,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 PEAK_HBM_GBS = 8000.0           # same guide, "HBM3E 8 TB/s peak" (about 6.3 TB/s achievable)
+LR_DEFAULT = 1e-6               # see scripts/exp_bench_regime.py / DESIGN.md section 6: keeps the loss off ln(B) with live gradients
 FLOP_PER_PAIR_STEP = 41.1e9     # 3 x (8.2 GFLOP ResNet-50+projector + 5.5 GFLOP CXR-BERT, L=32, no MLM head); SURVEY.md §8d
 
 
@@ -77,7 +85,10 @@ def parse():
     ap.add_argument("--seq-len", type=int, default=32)
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--temperature", type=float, default=0.07)
-    ap.add_argument("--cpu-baseline-batch", type=int, default=16)
+    ap.add_argument("--lr", type=float, default=LR_DEFAULT, help="Adam learning rate of the timed steps")
+    ap.add_argument("--no-bn-calibration", action="store_true", help="keep the name-keyed BatchNorm statistics of synthetic.fill_module_")
+    ap.add_argument("--cpu-baseline-batch", type=int, default=64)
+    ap.add_argument("--cpu-baseline-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--precision", default=os.environ.get("CXRK_PRECISION", "split_bf16"), choices=["split_bf16", "fp32"],
@@ -86,14 +97,14 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(batch: int, seq_len: int, image_size: int, tau: float):
+def cpu_baseline(batch: int, seq_len: int, image_size: int, tau: float, steps: int = 3):
     """The CPU oracle (PyTorch fp32, all host cores) timed on a bounded sample of the same workload: full-size models,
-    a global batch of `batch` pairs, 1 warm-up + 2 timed steps."""
+    a global batch of `batch` pairs, 1 warm-up + `steps` timed steps (>= 3 steps at batch 64 / 256)."""
     from incremental_multimodal_medical_learning_ii_amd import synthetic as syn
     from oracle import ref_image, ref_step, ref_text
     ncores = usable_cores()
     torch.set_num_threads(ncores)
-    log(f"cpu baseline: oracle joint step on {ncores} host threads, batch {batch}")
+    log(f"cpu baseline: oracle joint step on {ncores} host threads, batch {batch}, 1 + {steps} steps")
     prm, buf = ref_image.image_param_shapes()
     g = torch.Generator().manual_seed(27)
     ip = {k: (torch.randn(s, generator=g) * (0.05 if len(s) > 1 else 0.0) + (1.0 if len(s) == 1 else 0.0)) for k, s in prm.items()}
@@ -107,15 +118,18 @@ def cpu_baseline(batch: int, seq_len: int, image_size: int, tau: float):
     ids, mask = syn.synthetic_tokens(batch, seq_len)
     ref_step.joint_step(ip, tp, images, ids, mask, tau, opt)
     log("cpu baseline: warm-up step done")
-    t0 = time.perf_counter()
-    n = 2
-    for _ in range(n):
+    times = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
         ref_step.joint_step(ip, tp, images, ids, mask, tau, opt)
-    dt = (time.perf_counter() - t0) / n
-    return {"value": batch / dt, "unit": "images/sec", "cores": ncores, "kind": "port",
+        times.append(time.perf_counter() - t0)
+        log(f"cpu baseline: step {len(times)}/{steps}: {times[-1]:.2f} s")
+    dt = sum(times) / len(times)
+    return {"value": batch / dt, "unit": "images/sec", "cores": ncores, "kind": "port", "threads": ncores,
+            "s_per_step": dt, "s_per_step_each": [round(t, 3) for t in times], "batch": batch, "timed_steps": steps,
             "sample": f"oracle joint step (ResNet-50 {image_size}px + 12-layer CXR-BERT L={seq_len} + InfoNCE + Adam), global batch "
-                      f"{batch}, 1 warm-up + {n} timed steps, {dt:.2f} s/step; per-pair cost is batch-independent apart from "
-                      f"the negligible B^2 logits"}
+                      f"{batch}, 1 warm-up + {steps} timed steps, {dt:.2f} s/step on {ncores} threads; per-pair cost is "
+                      f"batch-independent apart from the negligible B^2 logits"}
 
 
 def _free_port() -> int:
@@ -163,9 +177,10 @@ def selftest_rank() -> None:
 
 def structured_images(batch: int, size: int, seed: int) -> torch.Tensor:
     """Synthetic 1-channel images replicated to 3 channels (reference: DataRetrieval.py:175-180) with per-image low-frequency
-    structure (a few random plane waves + noise, scaled into [0,1)), so that different images get different embeddings and the
-    contrastive loss has something to separate; iid-noise images (synthetic.synthetic_images, used by the parity fixtures) all map
-    to nearly the same embedding and pin the loss at ln(batch)."""
+    structure (a few random plane waves + noise, scaled into [0,1)): iid-noise images (synthetic.synthetic_images, used by the
+    parity fixtures) have the same statistics everywhere and an average-pooling encoder maps them all to nearly the same
+    embedding.  Structure in the input is necessary but not sufficient for distinct embeddings — the BatchNorm statistics have to
+    match the activations too (`ImageModel.calibrate_batchnorm_`, called by main())."""
     g = torch.Generator().manual_seed(seed)
     yy, xx = torch.meshgrid(torch.linspace(0, 1, size), torch.linspace(0, 1, size), indexing="ij")
     img = torch.zeros(batch, size, size)
@@ -178,6 +193,29 @@ def structured_images(batch: int, size: int, seed: int) -> torch.Tensor:
     img -= img.amin(dim=(1, 2), keepdim=True)
     img /= img.amax(dim=(1, 2), keepdim=True).clamp_min(1e-6) * 1.0001
     return img.unsqueeze(1).repeat_interleave(3, dim=1).contiguous()
+
+
+def cotangent_norms(trainer, images, ids, mask):
+    """||dL/dI||, ||dL/dT|| of the InfoNCE loss w.r.t. this rank's (un-normalised) embeddings at the current weights, the loss and
+    the mean off-diagonal cosine of the image / text embeddings: what the two encoders' backward passes are fed.  (No collectives
+    here: at N > 1 the loss is the local-batch one.)"""
+    from incremental_multimodal_medical_learning_ii_amd import functional as Fh
+    with torch.no_grad():
+        ie = trainer.image_model(images)
+        te = trainer.text_model.get_projected_text_embeddings(ids, mask, normalize_embeddings=False)
+    ie, te = ie.clone().requires_grad_(True), te.clone().requires_grad_(True)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return None
+    loss = Fh.infonce_loss(ie, te, trainer.temperature)
+    gi, gt = torch.autograd.grad(loss, (ie, te))
+
+    def offdiag(e):
+        n = torch.nn.functional.normalize(e.detach().double(), dim=1)
+        c = n @ n.T
+        return float((c.sum() - c.diagonal().sum()) / (c.numel() - c.shape[0]))
+    return {"loss": float(loss), "dL_dI": float(gi.norm()), "dL_dT": float(gt.norm()), "mean_offdiag_cos_image": offdiag(ie),
+            "mean_offdiag_cos_text": offdiag(te)}
 
 
 def secondary_metrics(args, dev, trainer, images, ids, mask, step_ms):
@@ -277,9 +315,16 @@ def main():
     cxr_lib.set_precision(args.precision)
     im = get_biovil_resnet(None).eval()         # BN on running statistics (the reference's only mode)
     tm = CXRBertModel(CXRBertConfig()).eval()   # dropout inactive
-    syn.fill_module_(im)                        # name-keyed deterministic weights, non-trivial BN statistics: identical replicas
-    syn.fill_module_(tm)                        # on every rank, and a loss that actually moves (the parity tests use the same fill)
-    trainer = JointContrastiveTrainer(im.to(dev), tm.to(dev), lr=1e-4, temperature=args.temperature)
+    syn.fill_module_(im)                        # name-keyed deterministic weights: identical replicas on every rank
+    syn.fill_module_(tm)                        # (the parity tests use the same fill)
+    im = im.to(dev)
+    if not args.no_bn_calibration:
+        # a trained checkpoint's BatchNorm statistics match its activations; the name-keyed fill's do not, and 53 mismatched
+        # BatchNorms in a row leave a common-mode component that makes all image embeddings parallel (cosine 1 - 1e-6): one Adam
+        # step at any usable learning rate then pins the loss at ln(B) with zero cotangents (round 2's bench).  One calibration
+        # pass over a fixed sample (same on every rank) gives the synthetic weights that property; it is set-up, not timed.
+        im.calibrate_batchnorm_(structured_images(64, args.image_size, seed=4242).to(dev))
+    trainer = JointContrastiveTrainer(im, tm.to(dev), lr=args.lr, temperature=args.temperature)
     B = args.batch_per_gpu
     NB = 4                                      # resident batches the steps rotate through
     batches = []
@@ -337,16 +382,41 @@ def main():
                                        "much when the forward changes in the last bits (ReLU / max-pool decisions on the other side of "
                                        "zero, DESIGN.md section 2); the split_bf16 rows above are to be read against it, not against `bar`"}}
         del vals
+        # the same question with the discontinuity taken out: the fp32 forward's ReLU / max-pool decisions imposed on the split-bf16
+        # backward (diagnostics.imposed_decision_gradient_errors), every image-encoder gradient tensor, cotangent = a fixed random one
+        try:
+            from incremental_multimodal_medical_learning_ii_amd.diagnostics import imposed_decision_gradient_errors
+            cot = torch.randn(images.shape[0], 128, generator=torch.Generator().manual_seed(5)).to(dev)
+            imp, free, flips, emb_err = imposed_decision_gradient_errors(trainer.image_model, images, cot)
+            worst = max(((max(v), k) for k, v in imp.items()), key=lambda t: t[0])
+            worst_free = max(((max(v), k) for k, v in free.items()), key=lambda t: t[0])
+            precision_check["under_fp32_decisions"] = {
+                "what": "split_bf16 backward with the exact-fp32 forward's ReLU masks / max-pool winners imposed, against the exact-fp32 "
+                        "backward: [max |diff| / max |ref|, ||diff|| / ||ref||] per tensor; worst = the largest of either over all "
+                        f"{len(imp)} image-encoder gradient tensors",
+                "decisions_overridden": flips, "image_embedding": emb_err,
+                "grad_image_layer4_conv3": imp[probe_names[0]], "grad_image_layer1_conv1": imp[probe_names[1]],
+                "grad_image_stem_conv1": imp["encoder.encoder.conv1.weight"], "worst": [worst[0], worst[1]],
+                "free_running_worst": [worst_free[0], worst_free[1]], "bar": 1e-3}
+            del imp, free, cot
+        except Exception as e:   # evidence, not the measurement
+            precision_check["under_fp32_decisions"] = {"error": repr(e)}
+        trainer.optimizer.zero_grad()
         log(f"precision check: {precision_check}")
 
     log(f"models + {NB} synthetic batches resident on the GPU; warm-up")
+    cot_before = cotangent_norms(trainer, images, ids, mask)
+    log(f"before the first step: {cot_before}")
     loss = None
     losses = []
+    warm_ms = []
     for i in range(args.warmup):
+        t_w = time.perf_counter()
         loss = trainer.step(*batches[i % NB])
         torch.cuda.synchronize()
+        warm_ms.append((time.perf_counter() - t_w) * 1e3)
         losses.append(float(loss))
-        log(f"warm-up step {i + 1}/{args.warmup} done, loss {float(loss):.4f}, "
+        log(f"warm-up step {i + 1}/{args.warmup} done in {warm_ms[-1]:.1f} ms, loss {float(loss):.4f}, "
             f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     sync()
     prof = (not args.no_roofline) and rank == 0
@@ -354,14 +424,35 @@ def main():
     if prof and single_stream:
         K.profiler.start()
     step_losses = []
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step device times, no host sync inside
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         step_losses.append(trainer.step(*batches[(args.warmup + i) % NB]))
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
     K.profiler.stop()
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     losses += [float(x) for x in step_losses]
-    log(f"timed region: {args.steps} steps in {dt:.2f} s; loss {losses[0]:.4f} -> {losses[-1]:.4f}")
+    log(f"timed region: {args.steps} steps in {dt:.2f} s; loss {losses[0]:.4f} -> {losses[-1]:.4f}; "
+        f"per step {' '.join(f'{x:.1f}' for x in step_ms)} ms")
+    cot_after = cotangent_norms(trainer, images, ids, mask)
+    log(f"after the timed region: {cot_after}")
+    import math
+    ln_b = math.log(world * B)
+    # collapsed embeddings (all parallel: uniform logits, loss = ln(global batch) EXACTLY and staying there, cotangents -> 0) must
+    # not be timed.  The loss may well pass through ln(B) on its way down, so the test is on what the backward is fed.
+    collapsed = not all(math.isfinite(x) for x in losses)
+    if cot_before is not None and cot_after is not None:
+        collapsed = collapsed or cot_after["dL_dI"] < 0.1 * cot_before["dL_dI"] or cot_after["dL_dT"] < 0.1 * cot_before["dL_dT"] \
+            or cot_after["mean_offdiag_cos_image"] > 0.9999 or cot_after["mean_offdiag_cos_text"] > 0.9999
+    else:
+        collapsed = collapsed or all(abs(x - ln_b) < 2e-5 for x in losses[-3:])
+    if collapsed:
+        raise SystemExit(f"[bench] the model collapsed during the run (loss trace {losses}, ln(global batch) = {ln_b:.5f}, cotangents "
+                         f"{cot_before} -> {cot_after}): with uniform logits the InfoNCE cotangents vanish and both encoders' backward "
+                         f"passes would be timed on zeros; refusing to report that number (lower --lr, or check the BatchNorm calibration)")
     prof_steps = args.steps
     if prof and not single_stream:
         # Per-kernel durations for the roofline: with the two encoders on two streams their kernels co-run, and an event
@@ -425,7 +516,9 @@ def main():
                                    "(BASELINE config 3 at N=1: batch 1024 on one MI355X; config 5 at N=8: global 8192)",
                        "global_batch": world * B, "batch_per_gpu": B, "seq_len": args.seq_len, "image_size": args.image_size,
                        "temperature": args.temperature, "parallelism": f"dp{world}",
-                       "weights": "name-keyed deterministic fill (synthetic.fill_module_), non-trivial BN statistics",
+                       "weights": "name-keyed deterministic fill (synthetic.fill_module_)" + ("" if args.no_bn_calibration else
+                                  "; BatchNorm running statistics calibrated on a 64-image sample (ImageModel.calibrate_batchnorm_)"),
+                       "optimizer": f"Adam, lr {args.lr:g}",
                        "batches": f"{NB} resident synthetic batches, rotated",
                        "batchnorm": "running statistics (eval mode), gamma/beta trained",
                        "precision": args.precision,
@@ -433,10 +526,14 @@ def main():
                                          "planes (4 B per element) and every product is hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 "
                                          "accumulation (~2^-16 relative); the parity suite (1e-3 relative on embeddings, loss, gradients) "
                                          "runs in both modes; fp32 = exact fp32 MFMA"},
-            "final_loss": final_loss, "loss_trace": [round(x, 5) for x in losses],
-            "loss_note": "random-initialised encoders map a batch to nearly parallel embeddings: the first Adam steps flatten the logits "
-                         "(loss -> ln(global batch)), which is where a contrastive run starts from; timing is data-independent, "
-                         "the numerical evidence is precision_check (taken at the initial weights) and the parity suite",
+            "final_loss": final_loss, "loss_trace": [round(x, 5) for x in losses], "ln_global_batch": round(ln_b, 5),
+            "lr": args.lr, "step_ms": [round(x, 2) for x in step_ms], "warmup_step_ms": [round(x, 1) for x in warm_ms],
+            "first_timed_step_ms": round(step_ms[0], 2), "steady_state_ms": round(sorted(step_ms)[len(step_ms) // 2], 2),
+            "cotangent_norm": {"before_first_step": cot_before, "after_timed_region": cot_after,
+                               "note": "norm of dL/d(embeddings) = what both encoders' backward passes are fed; 0 for a collapsed model"},
+            "loss_note": "BatchNorm statistics calibrated on a sample batch, Adam at --lr: the run stays in the first, descending phase of "
+                         "contrastive training (loss above ln(global batch) and falling, embeddings not parallel, cotangents O(1e-2..1)); "
+                         "bench.py exits with an error instead of a number when the embeddings collapse (cotangent norm < 10 % of the initial one)",
             "model_tflops_per_s": FLOP_PER_PAIR_STEP * world * B * args.steps / dt / 1e12,
         }
         if prof:
@@ -458,18 +555,24 @@ def main():
                 tot_fl = sum(v["flops"] for v in summ.values())
                 tot_by = sum(v["bytes"] for v in summ.values())
                 traffic = None
+                mfma_busy = None
                 try:  # HBM bytes per launch of this kernel from the committed PMC passes (scripts/pmc_traffic.sh)
                     pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
                     traffic = pmc["kernels"].get(key, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
+                try:  # SQ counters of the same kernel as it runs inside this step (scripts/pmc_sq.sh pointed at bench.py)
+                    sq = json.load(open(os.path.join(ROOT, "profiles", "pmc_sq.json")))
+                    mfma_busy = sq["kernels"].get(key)
+                except Exception:
+                    mfma_busy = None
                 mfma_note = ("algorithmic 2*M*N*K FLOPs against the dense bf16 MFMA peak / 3 (the split-bf16 mainloop executes 3 bf16 "
                              "MFMAs per product)") if bf16 else "exact fp32 MFMA, priced against the fp32 matrix peak"
                 hbm = frac_hbm >= frac_mfma
                 out["roofline"] = {"bound": "hbm" if hbm else "mfma",
                                    "achieved": gbps if hbm else tflops, "peak": PEAK_HBM_GBS if hbm else (peak_fl / 3.0 if bf16 else peak_fl),
                                    "unit": "GB/s" if hbm else "TFLOP/s", "frac": frac_hbm if hbm else frac_mfma,
-                                   "traffic": traffic, "kernel": key,
+                                   "traffic": traffic, "mfma_busy": mfma_busy, "kernel": key,
                                    "note": ("algorithmic bytes: every operand and fused side input (residual, ReLU bit mask) read once + "
                                             "the output written once, 4 B per element (1/8 B for masks); summed over the launches of this "
                                             "instantiation / their HIP-event time") if hbm else mfma_note,
@@ -496,7 +599,8 @@ def main():
             out["secondary"] = side
         if world == 1 and not args.no_cpu_baseline:   # the CPU leg runs at N=1 only
             try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch, args.seq_len, args.image_size, args.temperature)
+                out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch, args.seq_len, args.image_size, args.temperature,
+                                                   args.cpu_baseline_steps)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         faulthandler.cancel_dump_traceback_later()

@@ -148,7 +148,9 @@ int cxrk_spatial_mean_bwd_pl(const float* dy, const float* add, void* dx, long d
  * residual_ln: y = LayerNorm(x + res)                                             (BertSelfOutput / BertOutput)
  *              xhat, rstd saved for bwd; bwd: dx = LN'(dy) + dx_add, dgamma/dbeta reduced deterministically.
  * attn:        ctx = softmax(Q K^T / sqrt(d) + keymask) V per (sequence, head); qkv is the fused [T][3*nH*d]
- *              projection output; probs [B][nH][L][L] saved for bwd.  L <= 64, d <= 64 (multiple of 4).
+ *              projection output; probs [B][nH][L][L] saved for bwd.  d <= 64 (multiple of 4); L <= 64: one workgroup per
+ *              (sequence, head), everything in LDS; 64 < L <= 512 (the reference's max_position_embeddings,
+ *              text/inference_engine.py:30,44-46): tiled over 32 queries / 64 keys, bwd needs the dS workspace.
  * embed_bwd:   dword[ids[t]] += dx[t], summed in token order per row (sort by (id, position) + segmented sums: deterministic, no atomics)
  * Outputs declared `void* y, long yplane`: yplane = 0 -> fp32 tensor; yplane > 0 -> planes (bf16 hi at y, lo at y + yplane
  * elements), the format the following GEMM consumes in split-bf16 mode.
@@ -168,8 +170,9 @@ int cxrk_residual_ln_bwd(const float* dy, const float* xhat, const float* rstd, 
 int cxrk_planes_add_rows(const void* src, long plane, long rows, int cols, float* dst, long ld, hipStream_t stream);
 int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, int nH, int dH, void* ctx, long ctxplane, float* probs,
                   hipStream_t stream);
+size_t cxrk_attn_bwd_ws_bytes(int B, int L, int nH, int dH);
 int cxrk_attn_bwd(const float* qkv, const float* probs, const float* dctx, int B, int L, int nH, int dH, void* dqkv,
-                  long dqkvplane, hipStream_t stream);
+                  long dqkvplane, float* ws, size_t ws_bytes, hipStream_t stream);
 size_t cxrk_embed_bwd_ws_bytes(long T, int H);
 int cxrk_embed_bwd(const long* ids, const float* dx, long T, int H, float* dword, float* ws, size_t ws_bytes, hipStream_t stream);
 /* dx = dy * gelu'(pre): the erf-GELU between dense_to_hidden and LayerNorm of BertProjectionHead (modelling_cxrbert.py:45-46). */

@@ -11,6 +11,19 @@ What changed underneath (results identical):
   * `optim.Adam` / `optim.SGD` become one fused flat-buffer kernel; `myIncremental` a two-kernel reduction+restore.
 Plotting / t-SNE / heat-map reporting (`Trainer.py:1074-1185,1310-1554`) is host-side visualisation and is not part
 of this module; scalar metrics (sklearn) are kept.
+
+Two extensions behind the same entry points (both off unless asked for):
+  * `Trainer(..., joint_encoders={"image_model": ImageModel, "temperature": 0.07})` — the north-star step: both encoders train
+    in-loop.  Loaders then yield `(images [B,3,H,W], input_ids [B,L], attention_mask [B,L][, labels [B,5]])`; `train`,
+    `train_class_incremental` and `train_class_more_labels_incremental` run `contrastive.JointContrastiveTrainer.step` (ResNet-50 +
+    CXR-BERT forward, InfoNCE over the global batch, hand-written backward, fused Adam) per batch, with the reference's
+    iteration / logging / continual-learning bookkeeping around it; `val` / `test` embed the images with the trained image
+    model and score them against the class prompts embedded by the trained text model (the zero-shot chain of
+    `Trainer.py:797-837`).  The text model is the one inside `bert_encoder`.
+  * data parallelism: with `torch.distributed` initialised (one process per GPU) every rank draws the SAME global batch from its
+    loader (same sampler seed) and trains on its contiguous row shard; adapter gradients (0.5 MB) are summed with one
+    all-reduce of the flat gradient buffer, weighted by shard size, so the update equals the single-process global-batch one
+    (SURVEY.md §8e).  In joint mode the shards' embeddings are all-gathered for the global similarity matrix.
 """
 from __future__ import annotations
 
@@ -91,10 +104,14 @@ def change_values(tensor):
 
 
 class Trainer:
-    def __init__(self, single_prompt, prompts, class_names, loss_name, lr, device, writer, bert_encoder=None):
+    def __init__(self, single_prompt, prompts, class_names, loss_name, lr, device, writer, bert_encoder=None, joint_encoders=None,
+                 process_group=None):
         """Same positional arguments as the reference (`Trainer.py:101`).  `bert_encoder` (optional) injects a
         `TextInferenceEngine`; default `get_cxr_bert_inference()` as at `Trainer.py:109` (Hub fetch, or the offline
-        synthetic model when CXRK_SYNTHETIC_WEIGHTS=1)."""
+        synthetic model when CXRK_SYNTHETIC_WEIGHTS=1).  `joint_encoders` (optional, see the module docstring): a dict with
+        "image_model" (an `ImageModel` on `device`) and optionally "temperature" (default 0.07) — no adapters are created, the
+        trainable parameters are the two encoders.  `process_group`: the data-parallel group (default: the default group when
+        `torch.distributed` is initialised)."""
         self.pos_mean_counter = 0
         self.neg_mean_counter = 0
         self.n_reset = 0
@@ -123,8 +140,25 @@ class Trainer:
             print("*** ERROR... ***")
             raise Exception
 
+        import torch.distributed as dist
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        self._joint = None
+        self.image_model = None
+        if joint_encoders is not None:
+            from .contrastive import JointContrastiveTrainer
+            je = dict(joint_encoders) if isinstance(joint_encoders, dict) else {"image_model": joint_encoders[0], "temperature": joint_encoders[1]}
+            self.image_model = je["image_model"]
+            if OPTIM not in ("adam", "sgd"):
+                raise Exception
+            self._joint = JointContrastiveTrainer(self.image_model, self.bert_encoder.model, lr=lr,
+                                                  temperature=float(je.get("temperature", 0.07)), group=process_group, optim=OPTIM)
+            print("*** JOINT ENCODER TRAINING (InfoNCE over the global batch): no adapters ***")
         params = []
-        if SHARED:
+        if self._joint is not None:
+            self.image_adapter = self.text_adapter = None
+        elif SHARED:
             print("*** SHARED MODEL !!!! ***")
             shared_model = new_adapter()
             self.image_adapter = shared_model
@@ -147,7 +181,9 @@ class Trainer:
         self._has_txt = self.text_adapter is not None
         print("image adapter", self.image_adapter)
         print("text adapter", self.text_adapter)
-        if len(params) > 0:
+        if self._joint is not None:
+            self.optimizer = self._joint.optimizer
+        elif len(params) > 0:
             if OPTIM == "adam":
                 print("Creating Adam optimizer...")
                 self.optimizer = cxr_optim.Adam(params, lr=lr)
@@ -158,11 +194,17 @@ class Trainer:
                 raise Exception
         else:
             self.optimizer = None
+        if self.world > 1 and self.optimizer is not None:
+            # replicas must start identical: rank 0's initial weights everywhere (the drivers seed every rank alike, this makes it
+            # independent of that)
+            dist.broadcast(self.optimizer.flat_p, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                           group=process_group)
         self.val_f1_heat_map = torch.empty((0, 5))
         self.val_auroc_heat_map = torch.empty((0, 5))
         self.test_f1_heat_map = torch.empty((0, 5))
         self.test_auroc_heat_map = torch.empty((0, 5))
         self._bert_cache: Dict[tuple, torch.Tensor] = {}
+        self._flat_copy = None
         self._reset_counters = torch.zeros(2, dtype=torch.int64, device=device)
         self._reset_total = 0
 
@@ -212,6 +254,22 @@ class Trainer:
             g = torch.Generator().manual_seed(seed + 100 + i)
             out.append(DataLoader(TensorDataset(e, l), batch_size=bs, shuffle=shuffle, generator=g, num_workers=0,
                                   pin_memory=False, drop_last=False))
+        return out
+
+    @staticmethod
+    def synthetic_joint_loaders(n_train: int, n_val: int, n_test: int, batch_size: int, image_size: int = 224, seq_len: int = 32,
+                                vocab: int = 30522, seed: int = 27, eval_batch_size: int = 1024):
+        """Loaders for the joint-encoder mode (SURVEY.md §8d inputs): `(images [B,3,S,S] in [0,1) with one plane replicated to 3
+        channels, token ids [B,L], attention mask [B,L], multi-hot labels [B,5])`."""
+        from .synthetic import synthetic_images, synthetic_tokens
+        out = []
+        for i, (n, bs) in enumerate(((n_train, batch_size), (n_val, eval_batch_size), (n_test, eval_batch_size))):
+            ids, mask = synthetic_tokens(n, seq_len, vocab=vocab, seed=seed + 1 + 10 * i)
+            g = torch.Generator().manual_seed(seed + 2 + 10 * i)
+            labels = (torch.rand(n, 5, generator=g) < 0.3).float()
+            ds = TensorDataset(synthetic_images(n, image_size, seed=seed + 10 * i), ids, mask, labels)
+            gs = torch.Generator().manual_seed(seed + 100 + i)
+            out.append(DataLoader(ds, batch_size=bs, shuffle=True, generator=gs, num_workers=0, pin_memory=False, drop_last=False))
         return out
 
     @staticmethod
@@ -337,7 +395,7 @@ class Trainer:
             raise ValueError("Unsupported dataset type")
         loaders = []
         for i in range(5):
-            indices = torch.where(dataloader.dataset.tensors[1][:, i] == 1)[0]
+            indices = torch.where(dataloader.dataset.tensors[-1][:, i] == 1)[0]   # labels: the last tensor ([1] in the reference's pairs)
             subset = Subset(dataloader.dataset, indices)
             loaders.append(DataLoader(subset, batch_size=batch_size, sampler=RandomSampler(subset), num_workers=0,
                                       pin_memory=True, drop_last=False))
@@ -359,16 +417,15 @@ class Trainer:
         ds = dataloader.dataset
         if isinstance(ds, TensorDataset):
             return dataloader
-        inputs = [d.tensors[0] for d in ds.datasets]
-        targets = [d.tensors[1] for d in ds.datasets]
-        return DataLoader(TensorDataset(torch.cat(inputs), torch.cat(targets)), batch_size=dataloader.batch_size,
+        cols = [torch.cat([d.tensors[j] for d in ds.datasets]) for j in range(len(ds.datasets[0].tensors))]
+        return DataLoader(TensorDataset(*cols), batch_size=dataloader.batch_size,
                           num_workers=0, pin_memory=dataloader.pin_memory, drop_last=dataloader.drop_last)
 
     @staticmethod
     def count_positive_labels(dataloader):
         tot = torch.zeros(5)
-        for _, labels in dataloader:
-            tot += labels.sum(0)
+        for batch in dataloader:
+            tot += batch[-1].sum(0)
         for i in range(5):
             print(f"Label {i}: {tot[i]}")
 
@@ -381,7 +438,7 @@ class Trainer:
         hit = self._bert_cache.get(key)
         if hit is None:
             hit = self.bert_encoder.get_embeddings_from_prompt(list(prompts), normalize=False, verbose=False).to(self.device)
-            self._bert_cache[key] = hit
+            self._bert_cache[key] = hit   # (joint mode: emptied by every training step, the text encoder is no longer a constant)
         return hit
 
     def bert_forward_mean(self, pos_prompt, neg_prompt, use_grad, to_plot=False):
@@ -483,21 +540,60 @@ class Trainer:
 
     # ------------------------------------------------------------------------------------------------ hot loops
     def _set_mode(self, train: bool):
+        """adapters follow the loop (`Trainer.py:533-535,779-782`); in joint mode the encoders stay in eval mode throughout —
+        BatchNorm on running statistics, dropout off: the only mode the HIP path implements (parameters still get gradients)"""
         for m in (self.image_adapter, self.text_adapter):
             if m is not None:
                 m.train(train)
 
-    def _train_step(self, embs, labels, class_names, criterion):
-        self.optimizer.zero_grad()
-        embs = embs.to(self.device, non_blocking=True)
-        labels = labels.to(self.device, non_blocking=True)
-        new_embs = self.image_adapter(embs) if self._has_img else embs
+    def _shard(self, n: int):
+        """this rank's contiguous row range of a global batch of n rows (tensor_split boundaries)"""
+        return (self.rank * n) // self.world, ((self.rank + 1) * n) // self.world
+
+    def _train_step(self, batch, class_names, criterion, label_cols=None):
+        """One optimisation step on one loader batch.  Reference form: batch = (embs, labels), `label_cols` picks the label
+        column(s) of the task.  Joint form: batch = (images, input_ids, attention_mask[, labels])."""
         if self.loss_name != "standard":
             raise Exception
+        if self._joint is not None:
+            return self._joint_step(batch)
+        embs, labels = batch
+        if label_cols is not None:
+            labels = labels[:, label_cols]
+        n = embs.shape[0]
+        lo, hi = self._shard(n) if self.world > 1 else (0, n)
+        self.optimizer.zero_grad()
+        embs = embs[lo:hi].to(self.device, non_blocking=True)
+        labels = labels[lo:hi].to(self.device, non_blocking=True)
+        new_embs = self.image_adapter(embs) if self._has_img else embs
         logits, loss, _ = self._logits_and_loss(new_embs, labels, class_names, criterion, use_grad=True)
         loss.backward()
+        if self.world > 1:
+            # mean over the GLOBAL batch = sum over ranks of (rows of the shard / rows of the batch) x shard mean
+            import torch.distributed as dist
+            w = (hi - lo) / float(n)
+            self.optimizer.all_reduce_grads(self.group, pre_scale=w)
+            loss = K.scale_mask(loss.detach().reshape(1), alpha=w).reshape(())
+            dist.all_reduce(loss, group=self.group)
         self.optimizer.step()
         return loss.detach()
+
+    def _joint_step(self, batch):
+        """The north-star step on one batch `(images, input_ids, attention_mask[, labels])`: this rank's row shard through both
+        encoders, InfoNCE over the global batch, backward, gradient all-reduce, fused optimiser step."""
+        if len(batch) < 3:
+            raise ValueError("joint-encoder training expects loaders that yield (images, input_ids, attention_mask[, labels]); got a "
+                             f"batch of {len(batch)} tensors")
+        images, ids, mask = batch[0], batch[1], batch[2]
+        n = images.shape[0]
+        lo, hi = self._shard(n) if self.world > 1 else (0, n)
+        if self.world > 1 and n % self.world:
+            raise ValueError(f"joint-encoder training shards the batch evenly: {n} rows over {self.world} ranks (use drop_last)")
+        dev = self.device
+        loss = self._joint.step(images[lo:hi].to(dev, non_blocking=True), ids[lo:hi].to(dev, non_blocking=True),
+                                mask[lo:hi].to(dev, non_blocking=True))
+        self._bert_cache.clear()
+        return loss
 
     def train(self, train_loader, criterion, epoch, CONTINUAL_LEARNING=None, threshold=None, scheduler=None, part=None,
               epochs=None, actual_task=None):
@@ -506,11 +602,11 @@ class Trainer:
         iteration = 0
         self._set_mode(True)
         cl = CONTINUAL_LEARNING == "myCL" and actual_task is not None and actual_task > 1
-        for embs, labels in train_loader:
+        for batch in train_loader:
             if cl:
                 self.model_copy()
             batch_idx += 1
-            loss = self._train_step(embs, labels, self.class_names, criterion)
+            loss = self._train_step(batch, self.class_names, criterion)
             if part is None:
                 iteration = (epoch - 1) * len(train_loader) + batch_idx
             else:
@@ -532,11 +628,11 @@ class Trainer:
         self._set_mode(True)
         cl = CONTINUAL_LEARNING == "myCL" and actual_task is not None and actual_task > 1
         names = [self.class_names[current_task]]
-        for embs, labels in train_loader:
+        for batch in train_loader:
             if cl:
                 self.model_copy()
             batch_idx += 1
-            loss = self._train_step(embs, labels[:, current_task], names, criterion)
+            loss = self._train_step(batch, names, criterion, label_cols=current_task)
             if cl:
                 self.myIncremental(threshold, batch_idx)
             if self.writer is not None:
@@ -552,11 +648,11 @@ class Trainer:
         self._set_mode(True)
         cl = CONTINUAL_LEARNING == "myCL" and actual_task is not None and actual_task > 1
         names = self.class_names[:current_task + 1]
-        for embs, labels in train_loader:
+        for batch in train_loader:
             if cl:
                 self.model_copy()
             batch_idx += 1
-            loss = self._train_step(embs, labels[:, :current_task + 1], names, criterion)
+            loss = self._train_step(batch, names, criterion, label_cols=slice(0, current_task + 1))
             if cl:
                 self.myIncremental(threshold, batch_idx)
             if self.writer is not None:
@@ -570,11 +666,16 @@ class Trainer:
         self._set_mode(False)
         y_true, y_pred, y_score = [], [], []
         batch_idx = 0
-        for embs, labels in loader:
+        for batch in loader:
             batch_idx += 1
-            embs = embs.to(self.device)
-            labels = labels.to(self.device)
-            new_embs = self.image_adapter(embs) if self._has_img else embs
+            labels = batch[-1].to(self.device)
+            if self._joint is not None:
+                if len(batch) < 4:
+                    raise ValueError("joint-encoder evaluation needs (images, input_ids, attention_mask, labels) batches")
+                new_embs = self.image_model(batch[0].to(self.device))   # (under no_grad: the whole loop is)
+            else:
+                embs = batch[0].to(self.device)
+                new_embs = self.image_adapter(embs) if self._has_img else embs
             logits, loss, cos = self._logits_and_loss(new_embs, labels, self.class_names, criterion, use_grad=False)
             if cos.shape[1] == 2 * len(self.class_names) and TRAIN_LOGIT_DIFF:
                 score, pred = K.eval_score(cos.contiguous(), PRED_LOGIT_DIFF)
@@ -624,6 +725,8 @@ class Trainer:
             self.image_adapter_copy = [p.detach().clone() for p in self.image_adapter.parameters()]
         if self._has_txt:
             self.text_adapter_copy = [p.detach().clone() for p in self.text_adapter.parameters()]
+        if self._joint is not None:   # both encoders: one copy of the flat parameter buffer (0.5 GB)
+            self._flat_copy = self.optimizer.flat_p.detach().clone()
         self.n_reset = 0
         self.n_updated = 0
         self._reset_counters.zero_()
@@ -637,6 +740,13 @@ class Trainer:
             for p, old in zip(mod.parameters(), snap):
                 K.weight_reset(p.data, old, threshold, self._reset_counters)
                 self._reset_total += p.numel()
+        if self._joint is not None and self._flat_copy is not None:
+            # per parameter tensor, as in the reference: each tensor is one gap-free slice of the flat buffer and of its copy
+            flat, base = self.optimizer.flat_p, self.optimizer.flat_p.data_ptr()
+            for p in self.optimizer.params:
+                o, n = (p.data_ptr() - base) // 4, p.numel()
+                K.weight_reset(flat[o:o + n], self._flat_copy[o:o + n], threshold, self._reset_counters)
+                self._reset_total += n
 
     @torch.no_grad()
     def myIncremental(self, threshold, iteration):
@@ -678,6 +788,9 @@ class Trainer:
             torch.save(self.image_adapter.state_dict(), os.path.join(self.writer.log_dir, 'image_adapter.pt'))
         if self._has_txt:
             torch.save(self.text_adapter.state_dict(), os.path.join(self.writer.log_dir, 'text_adapter.pt'))
+        if self._joint is not None and self.rank == 0:
+            torch.save(self.image_model.state_dict(), os.path.join(self.writer.log_dir, 'image_model.pt'))
+            torch.save(self.bert_encoder.model.state_dict(), os.path.join(self.writer.log_dir, 'text_model.pt'))
         if hasattr(self.writer, "flush"):
             self.writer.flush()
 
@@ -687,7 +800,14 @@ class Trainer:
         adapter).  Files are opened with `weights_only=True`: a pickled module, as the reference writes, is refused."""
         for has, mod, name in ((self._has_img, self.image_adapter, 'image_adapter.pt'), (self._has_txt, self.text_adapter, 'text_adapter.pt')):
             if has:
-                sd = torch.load(os.path.join(self.writer.log_dir, name), map_location="cpu", weights_only=True)
-                if not isinstance(sd, dict):
-                    raise ValueError(f"{name}: expected a state dict of tensors")
+                path = os.path.join(self.writer.log_dir, name)
+                try:
+                    sd = torch.load(path, map_location="cpu", weights_only=True)
+                except Exception as e:   # a whole-module pickle, as the reference's save() writes (Trainer.py:1646-1648)
+                    raise ValueError(f"{path}: not a tensors-only state dict ({type(e).__name__}).  This package stores "
+                                     f"`module.state_dict()` under the reference's file names and opens files with weights_only=True; "
+                                     f"a file written by the reference's Trainer.save() is a pickled `models.myMLP` module — convert it "
+                                     f"in the reference environment (INTEGRATION.md, 'Adapter checkpoints') before loading it here") from e
+                if not isinstance(sd, dict) or not all(isinstance(v, torch.Tensor) for v in sd.values()):
+                    raise ValueError(f"{path}: expected a state dict of tensors (see INTEGRATION.md, 'Adapter checkpoints')")
                 mod.load_state_dict(sd)

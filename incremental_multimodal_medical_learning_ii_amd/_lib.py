@@ -51,7 +51,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_residual_ln_bwd": (I, [P, P, P, P, L, I, P, P, L, P, P, I, P, I, P, Z, P]),
     "cxrk_planes_add_rows": (I, [P, L, L, I, P, L, P]),
     "cxrk_attn_fwd": (I, [P, P, I, I, I, I, P, L, P, P]),
-    "cxrk_attn_bwd": (I, [P, P, P, I, I, I, I, P, L, P]),
+    "cxrk_attn_bwd_ws_bytes": (Z, [I, I, I, I]),
+    "cxrk_attn_bwd": (I, [P, P, P, I, I, I, I, P, L, P, Z, P]),
     "cxrk_embed_bwd_ws_bytes": (Z, [L, I]),
     "cxrk_embed_bwd": (I, [P, P, L, I, P, P, Z, P]),
     "cxrk_gelu_bwd": (I, [P, P, L, P, P]),

@@ -23,7 +23,8 @@ from . import optim as cxr_optim
 
 class JointContrastiveTrainer:
     def __init__(self, image_model: torch.nn.Module, text_model: torch.nn.Module, lr: float = 1e-4,
-                 temperature: float = 0.07, group=None, train_mlm_head: bool = False, two_streams: Optional[bool] = None):
+                 temperature: float = 0.07, group=None, train_mlm_head: bool = False, two_streams: Optional[bool] = None,
+                 optim: str = "adam"):
         self.image_model, self.text_model = image_model, text_model
         self.temperature, self.group = temperature, group
         import os
@@ -31,24 +32,43 @@ class JointContrastiveTrainer:
         self._text_stream = None
         image_model.prepare_()
         text_model.prepare_()
-        params = [p for n, p in image_model.named_parameters() if not n.startswith("encoder.encoder.fc.")]
+        inamed = [(n, p) for n, p in image_model.named_parameters() if not n.startswith("encoder.encoder.fc.")]
+        params = [p for _, p in inamed]
         tparams = []
         for n, p in text_model.named_parameters():
             if n.startswith("cls.predictions.") and not train_mlm_head:
                 continue  # MLM head: no gradient on this path
             tparams.append(p)
-        self.optimizer = cxr_optim.Adam(params + tparams, lr=lr)
+        if optim == "adam":          # the reference's `optim.Adam(params, lr)` / `optim.SGD(params, lr)` (Trainer.py:172-178)
+            self.optimizer = cxr_optim.Adam(params + tparams, lr=lr)
+        elif optim == "sgd":
+            self.optimizer = cxr_optim.SGD(params + tparams, lr=lr)
+        else:
+            raise ValueError(f"optim must be 'adam' or 'sgd', got {optim!r}")
         text_model.prepare_()
         self.world = 1
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():
             self.world = dist.get_world_size(group)
-        # Data-parallel overlap: the text encoder's backward (~1/3 of the step's backward) finishes long before the image
-        # encoder's; its 0.44 GB of gradients are one gap-free range of the flat buffer and are all-reduced as soon as they are
-        # complete (hook at the end of the text backward, on the text stream), under the image backward.  Only the image
-        # encoder's 0.1 GB remains to be reduced after backward() returns.
-        self._text_span = self.optimizer.grad_span(tparams) if self.world > 1 else None
-        self._early = None
+        self._spans = self.reduce_spans(inamed, tparams) if self.world > 1 else {}
+
+    def reduce_spans(self, inamed=None, tparams=None) -> dict:
+        """{tag: (lo, hi)} element ranges of the flat gradient buffer that become complete together during `backward()`, in the
+        order they complete: "text" (the whole text encoder: its backward is a third of the step's and ends first), then the
+        image encoder from the back: "head" (projector + layer4), "layer3", "layer2", "stem" (layer1 + stem).  Each range is
+        all-reduced as soon as its gradients are complete (hooks on the encoders' backward, see `step`), under the rest of the
+        backward; a tag whose parameters do not form one gap-free range is left to the final reduce."""
+        from .image_encoder import stage_of_param
+        if inamed is None:
+            inamed = [(n, p) for n, p in self.image_model.named_parameters() if not n.startswith("encoder.encoder.fc.")]
+        if tparams is None:
+            ids = {id(p) for p in self.optimizer.params}
+            tparams = [p for p in self.text_model.parameters() if id(p) in ids]
+        groups = {"text": list(tparams)}
+        for n, p in inamed:
+            groups.setdefault(stage_of_param(n), []).append(p)
+        spans = {tag: self.optimizer.grad_span(ps) for tag, ps in groups.items()}
+        return {tag: sp for tag, sp in spans.items() if sp is not None}
 
     def forward_loss(self, images: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
         """The two encoders are independent up to the loss, so the text encoder runs on a second HIP stream: the tail of one
@@ -70,24 +90,39 @@ class JointContrastiveTrainer:
         return Fh.infonce_loss(img, txt, self.temperature, self.group)
 
     def step(self, images: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
-        """One optimisation step on this rank's shard; returns the global-batch loss (device scalar, no host sync)."""
+        """One optimisation step on this rank's shard; returns the global-batch loss (device scalar, no host sync).
+
+        Data-parallel overlap (N > 1): the gradient all-reduce of a range of the flat buffer (`reduce_spans`) is started by the
+        backward itself the moment that range is complete — a callable handed to THIS step's two encoder calls and carried by
+        their autograd nodes (no module-level state): the text encoder's 0.44 GB under the image backward, then the image
+        encoder's stages from the back (60 / 28 / 5 / 1 MB) under the layers in front of them; what is left (nothing, when every
+        tag fired) is reduced after `backward()` returns.  Precondition, asserted: each encoder runs ONCE per step inside
+        `forward_loss` — a second call of an encoder in the same graph would have its range reduced before the second
+        contribution was accumulated."""
         self.optimizer.zero_grad()
-        loss = self.forward_loss(images, input_ids, attention_mask)
-        if self.world > 1 and self._text_span is not None:
-            from . import text_encoder as TE
-            self._early = None
+        if self.world > 1 and self._spans:
+            works, fired = [], []
 
-            def start_text_reduce():
-                self._early = self.optimizer.all_reduce_span(self._text_span[0], self._text_span[1], self.group)
+            def on_ready(tag: str) -> None:
+                span = self._spans.get(tag)
+                if span is None:
+                    return
+                if tag in fired:
+                    raise RuntimeError(f"JointContrastiveTrainer.step: the gradients of '{tag}' were reported complete twice in one "
+                                       f"backward (an encoder was called more than once in this step's graph)")
+                fired.append(tag)
+                works.extend(self.optimizer.all_reduce_span(span[0], span[1], self.group))
 
-            TE.after_backward = start_text_reduce
+            self.image_model.grad_ready_hook = self.text_model.grad_ready_hook = on_ready
             try:
-                loss.backward()
+                loss = self.forward_loss(images, input_ids, attention_mask)   # the hook is captured by the two autograd nodes here
             finally:
-                TE.after_backward = None
-            early = self._early
-            self.optimizer.all_reduce_grads(self.group, skip=self._text_span if early is not None else None, pending=early)
+                self.image_model.grad_ready_hook = self.text_model.grad_ready_hook = None
+            loss.backward()
+            self.last_overlapped = tuple(fired)
+            self.optimizer.all_reduce_grads(self.group, skip=[self._spans[t] for t in fired], pending=works)
         else:
+            loss = self.forward_loss(images, input_ids, attention_mask)
             loss.backward()
             if self.world > 1:
                 self.optimizer.all_reduce_grads(self.group)

@@ -440,6 +440,237 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   }
 }
 
+// ---- sequences of 64 < L <= ALONG tokens (the reference tokenizer accepts prompts up to max_position_embeddings = 512,
+// text/inference_engine.py:30,44-46): a head no longer fits in LDS, so the work is tiled.  Forward: one workgroup per (sequence,
+// head, tile of TQ = 32 queries) keeps its 32 full score rows in LDS ([32][L + 1] floats), streams the keys and then the values
+// through a 64-row LDS tile, and applies the same full-row softmax (maximum subtracted, finite mask constant) as the short kernel.
+// Backward, without atomics: a query-tile kernel forms t_i = sum_j P_ij dP_ij, dS = P o (dP - t) * scale (written to a workspace)
+// and dQ; a key-tile kernel then sums dK = dS^T Q and dV = P^T dO over the query tiles in ascending order.
+constexpr int ALONG = 512;
+constexpr int TQ = 32, TK = 64;
+
+// rows [r0, r0 + nrows) of one head's [L][dH] slice (row stride ld) -> dst[nrows][ALD]; rows >= L are zero
+__device__ __forceinline__ void load_rows(float* dst, const float* src, long ld, int r0, int nrows, int L, int d4, int ALD) {
+  for (int i = threadIdx.x; i < nrows * d4; i += 256) {
+    const int row = i / d4, c4 = i % d4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + row < L) v = *reinterpret_cast<const float4*>(src + (long)(r0 + row) * ld + c4 * 4);
+    *reinterpret_cast<float4*>(dst + row * ALD + c4 * 4) = v;
+  }
+}
+// o[c] = <X[i], Y[jg + 8 c]> for c = 0..7 (X, Y rows of ALD floats in LDS)
+__device__ __forceinline__ void dot1x8(const float* X, const float* Y, int ALD, int d4n, int i, int jg, float (&o)[8]) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) o[c] = 0.f;
+  const float4* x = reinterpret_cast<const float4*>(X + i * ALD);
+  for (int d = 0; d < d4n; ++d) {
+    const float4 a = x[d];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = dot4(a, reinterpret_cast<const float4*>(Y + (jg + 8 * c) * ALD)[d], o[c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_long_kernel(const float* __restrict__ qkv, const long* __restrict__ mask, int L, int nH,
+                                                            int dH, float scale, float* __restrict__ ctx,
+                                                            unsigned short* __restrict__ ctxp, long ctxplane, float* __restrict__ probs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ALD = dH + 4, d4 = dH / 4, LP = L + 1;
+  float* Qs = smem; float* Ts = Qs + TQ * ALD; float* Ps = Ts + TK * ALD;     // Ps[TQ][L + 1]
+  const int nqt = (L + TQ - 1) / TQ;
+  const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt;
+  const int b = bh / nH, hd = bh % nH;
+  const int ld = 3 * nH * dH;
+  const float* base = qkv + (long)b * L * ld + hd * dH;
+  const int q0 = qt * TQ;
+  const int i = threadIdx.x >> 3, sub = threadIdx.x & 7;      // query row of the tile, lane of the row
+  constexpr float MASKED = -3.4028234663852886e38f;
+  load_rows(Qs, base, ld, q0, TQ, L, d4, ALD);
+  for (int k0 = 0; k0 < L; k0 += TK) {
+    __syncthreads();                                            // Qs ready / previous key tile consumed
+    load_rows(Ts, base + nH * dH, ld, k0, TK, L, d4, ALD);
+    __syncthreads();
+    float o[8];
+    dot1x8(Qs, Ts, ALD, d4, i, sub, o);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int j = k0 + sub + 8 * c;
+      if (j < L) Ps[i * LP + j] = (mask && mask[(long)b * L + j] == 0) ? MASKED : o[c] * scale;
+    }
+  }
+  __syncthreads();
+  {   // softmax of row i: 8 lanes
+    float m = -INFINITY;
+    for (int j = sub; j < L; j += 8) m = fmaxf(m, Ps[i * LP + j]);
+    m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
+    float sum = 0.f;
+    for (int j = sub; j < L; j += 8) { const float pv = expf(Ps[i * LP + j] - m); Ps[i * LP + j] = pv; sum += pv; }
+    sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+    const float inv = 1.0f / sum;
+    for (int j = sub; j < L; j += 8) {
+      const float pv = Ps[i * LP + j] * inv;
+      Ps[i * LP + j] = pv;
+      if (probs && q0 + i < L) probs[(((long)b * nH + hd) * L + q0 + i) * L + j] = pv;
+    }
+  }
+  float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};   // columns 4*sub.. and 4*(sub + 8)..
+  for (int k0 = 0; k0 < L; k0 += TK) {
+    __syncthreads();                                            // softmax done / previous value tile consumed
+    load_rows(Ts, base + 2 * nH * dH, ld, k0, TK, L, d4, ALD);
+    __syncthreads();
+    const int jn = min(TK, L - k0);
+    for (int j = 0; j < jn; ++j) {
+      const float pv = Ps[i * LP + k0 + j];
+      if (sub < d4) fma4(acc[0], pv, *reinterpret_cast<const float4*>(Ts + j * ALD + sub * 4));
+      if (sub + 8 < d4) fma4(acc[1], pv, *reinterpret_cast<const float4*>(Ts + j * ALD + (sub + 8) * 4));
+    }
+  }
+  if (q0 + i < L) {
+    const long obase = (long)b * L * (nH * dH) + hd * dH + (long)(q0 + i) * (nH * dH);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int dq = sub + 8 * h;
+      if (dq >= d4) continue;
+      if (ctxp) { const float v[4] = {acc[h].x, acc[h].y, acc[h].z, acc[h].w}; planes_store4(ctxp, ctxplane, obase + dq * 4, v); }
+      else *reinterpret_cast<float4*>(ctx + obase + dq * 4) = acc[h];
+    }
+  }
+}
+
+// query-tile pass of the backward: dS rows -> ws [B][nH][L][L], dQ
+__global__ __launch_bounds__(256) void attn_bwd_long_q_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
+                                                              const float* __restrict__ dctx, int L, int nH, int dH, float scale,
+                                                              float* __restrict__ dS, float* __restrict__ dqkv,
+                                                              unsigned short* __restrict__ dqkvp, long dqkvplane) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ALD = dH + 4, d4 = dH / 4, DP = TK + 1;
+  float* Os = smem; float* Ks = Os + TQ * ALD; float* Vs = Ks + TK * ALD; float* Ds = Vs + TK * ALD;   // Ds[TQ][TK + 1]
+  const int nqt = (L + TQ - 1) / TQ;
+  const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt;
+  const int b = bh / nH, hd = bh % nH;
+  const int ld = 3 * nH * dH;
+  const float* base = qkv + (long)b * L * ld + hd * dH;
+  const float* dob = dctx + (long)b * L * (nH * dH) + hd * dH;
+  const float* pb = probs + ((long)b * nH + hd) * L * L;
+  float* dsb = dS + ((long)b * nH + hd) * L * L;
+  const int q0 = qt * TQ;
+  const int i = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  const bool rowok = q0 + i < L;
+  load_rows(Os, dob, nH * dH, q0, TQ, L, d4, ALD);
+  // pass 1: t_i = sum_j P_ij * <dO_i, V_j>
+  float t = 0.f;
+  for (int k0 = 0; k0 < L; k0 += TK) {
+    __syncthreads();
+    load_rows(Vs, base + 2 * nH * dH, ld, k0, TK, L, d4, ALD);
+    __syncthreads();
+    float o[8];
+    dot1x8(Os, Vs, ALD, d4, i, sub, o);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int j = k0 + sub + 8 * c;
+      if (rowok && j < L) t = fmaf(pb[(long)(q0 + i) * L + j], o[c], t);
+    }
+  }
+  t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+  // pass 2: dS tile by tile, dQ_i += dS_ij K_j
+  float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  for (int k0 = 0; k0 < L; k0 += TK) {
+    __syncthreads();
+    load_rows(Ks, base + nH * dH, ld, k0, TK, L, d4, ALD);
+    load_rows(Vs, base + 2 * nH * dH, ld, k0, TK, L, d4, ALD);
+    __syncthreads();
+    float o[8];
+    dot1x8(Os, Vs, ALD, d4, i, sub, o);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int jl = sub + 8 * c, j = k0 + jl;
+      float v = 0.f;
+      if (rowok && j < L) {
+        v = pb[(long)(q0 + i) * L + j] * (o[c] - t) * scale;
+        dsb[(long)(q0 + i) * L + j] = v;
+      }
+      Ds[i * DP + jl] = v;
+    }
+    __syncthreads();
+    for (int j = 0; j < TK; ++j) {
+      const float dv = Ds[i * DP + j];
+      if (sub < d4) fma4(acc[0], dv, *reinterpret_cast<const float4*>(Ks + j * ALD + sub * 4));
+      if (sub + 8 < d4) fma4(acc[1], dv, *reinterpret_cast<const float4*>(Ks + j * ALD + (sub + 8) * 4));
+    }
+  }
+  if (rowok) {
+    const long qoff = (long)b * L * ld + hd * dH + (long)(q0 + i) * ld;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int dq = sub + 8 * h;
+      if (dq >= d4) continue;
+      if (dqkvp) { const float v[4] = {acc[h].x, acc[h].y, acc[h].z, acc[h].w}; planes_store4(dqkvp, dqkvplane, qoff + dq * 4, v); }
+      else *reinterpret_cast<float4*>(dqkv + qoff + dq * 4) = acc[h];
+    }
+  }
+}
+
+// key-tile pass of the backward: dK_j = sum_i dS_ij Q_i, dV_j = sum_i P_ij dO_i (query tiles in ascending order)
+__global__ __launch_bounds__(256) void attn_bwd_long_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ probs,
+                                                               const float* __restrict__ dS, const float* __restrict__ dctx, int L,
+                                                               int nH, int dH, float* __restrict__ dqkv,
+                                                               unsigned short* __restrict__ dqkvp, long dqkvplane) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ALD = dH + 4, d4 = dH / 4, DP = TK + 1;
+  float* Qs = smem; float* Os = Qs + TQ * ALD; float* Pt = Os + TQ * ALD; float* Dt = Pt + TQ * DP;   // Pt, Dt: [TQ][TK + 1]
+  const int nkt = (L + TK - 1) / TK;
+  const int kt = blockIdx.x % nkt, bh = blockIdx.x / nkt;
+  const int b = bh / nH, hd = bh % nH;
+  const int ld = 3 * nH * dH;
+  const float* base = qkv + (long)b * L * ld + hd * dH;
+  const float* dob = dctx + (long)b * L * (nH * dH) + hd * dH;
+  const float* pb = probs + ((long)b * nH + hd) * L * L;
+  const float* dsb = dS + ((long)b * nH + hd) * L * L;
+  const int k0 = kt * TK;
+  const int jr = threadIdx.x >> 2, sub = threadIdx.x & 3;     // key row of the tile, lane of the row: columns 4*(sub + 4 h)..
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 dk[4] = {z, z, z, z}, dv[4] = {z, z, z, z};
+  for (int q0 = 0; q0 < L; q0 += TQ) {
+    __syncthreads();
+    load_rows(Qs, base, ld, q0, TQ, L, d4, ALD);
+    load_rows(Os, dob, nH * dH, q0, TQ, L, d4, ALD);
+    for (int e = threadIdx.x; e < TQ * TK; e += 256) {
+      const int ii = e / TK, jj = e % TK;
+      const bool ok = q0 + ii < L && k0 + jj < L;
+      const long o = (long)(q0 + ii) * L + k0 + jj;
+      Pt[ii * DP + jj] = ok ? pb[o] : 0.f;
+      Dt[ii * DP + jj] = ok ? dsb[o] : 0.f;
+    }
+    __syncthreads();
+    for (int ii = 0; ii < TQ; ++ii) {
+      const float pv = Pt[ii * DP + jr], dsv = Dt[ii * DP + jr];
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const int dq = sub + 4 * h;
+        if (dq < d4) {
+          fma4(dk[h], dsv, *reinterpret_cast<const float4*>(Qs + ii * ALD + dq * 4));
+          fma4(dv[h], pv, *reinterpret_cast<const float4*>(Os + ii * ALD + dq * 4));
+        }
+      }
+    }
+  }
+  if (k0 + jr < L) {
+    const long koff = (long)b * L * ld + hd * dH + (long)(k0 + jr) * ld;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int dq = sub + 4 * h;
+      if (dq >= d4) continue;
+      if (dqkvp) {
+        const float a[4] = {dk[h].x, dk[h].y, dk[h].z, dk[h].w}, c[4] = {dv[h].x, dv[h].y, dv[h].z, dv[h].w};
+        planes_store4(dqkvp, dqkvplane, koff + nH * dH + dq * 4, a);
+        planes_store4(dqkvp, dqkvplane, koff + 2 * nH * dH + dq * 4, c);
+      } else {
+        *reinterpret_cast<float4*>(dqkv + koff + nH * dH + dq * 4) = dk[h];
+        *reinterpret_cast<float4*>(dqkv + koff + 2 * nH * dH + dq * 4) = dv[h];
+      }
+    }
+  }
+}
+
 // dst[r*ld + c] += src[r][c]  (src planes [rows][cols], cols % 8 == 0): adds a small planes tensor into strided rows of an fp32 one
 // (the CLS rows of a [N, L, H] gradient)
 __global__ void planes_add_rows_kernel(const unsigned short* __restrict__ src, long plane, long rows, int cols, float* __restrict__ dst,
@@ -554,8 +785,21 @@ extern "C" int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, i
   CXRK_CHECK_ARG(qkv && ctxv && B > 0 && nH > 0 && aligned16(qkv) && aligned16(ctxv) && ctxplane >= 0 && (ctxplane % 4) == 0);
   float* ctx = ctxplane ? nullptr : static_cast<float*>(ctxv);
   unsigned short* ctxp = ctxplane ? static_cast<unsigned short*>(ctxv) : nullptr;
-  if (dH > AD || dH < 4 || (dH % 4) != 0 || L > AL || L < 1) return CXRK_ERR_UNSUPPORTED;
+  if (dH > AD || dH < 4 || (dH % 4) != 0 || L > ALONG || L < 1) return CXRK_ERR_UNSUPPORTED;
   const int ALD = dH + 4;
+  if (L > AL) {   // tiled form: one workgroup per (sequence, head, 32 queries)
+    const size_t shl = (size_t)((TQ + TK) * ALD + TQ * (L + 1)) * sizeof(float);
+    static bool attr_long = false;
+    if (!attr_long) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_long_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(((TQ + TK) * (AD + 4) + TQ * (ALONG + 1)) * sizeof(float)));
+      attr_long = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_long_kernel, dim3((unsigned)(B * nH * ceil_div(L, TQ))), dim3(256), shl, stream, qkv, mask, L, nH, dH,
+                       1.0f / sqrtf((float)dH), ctx, ctxp, ctxplane, probs);
+    CXRK_LAUNCH_CHECK();
+    return CXRK_OK;
+  }
   const size_t sh = (size_t)(3 * L * ALD + L * (L + 1)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -569,14 +813,33 @@ extern "C" int cxrk_attn_fwd(const float* qkv, const long* mask, int B, int L, i
   return CXRK_OK;
 }
 
+// workspace of cxrk_attn_bwd: the dS matrix of the tiled form (L > 64); nothing for short sequences
+extern "C" size_t cxrk_attn_bwd_ws_bytes(int B, int L, int nH, int dH) {
+  (void)dH;
+  return L > AL ? (size_t)B * nH * L * L * sizeof(float) : 0;
+}
+
 extern "C" int cxrk_attn_bwd(const float* qkv, const float* probs, const float* dctx, int B, int L, int nH, int dH,
-                             void* dqkvv, long dqkvplane, hipStream_t stream) {
+                             void* dqkvv, long dqkvplane, float* ws, size_t ws_bytes, hipStream_t stream) {
   CXRK_CHECK_ARG(qkv && probs && dctx && dqkvv && B > 0 && nH > 0 && aligned16(qkv) && aligned16(dctx) && aligned16(dqkvv) && dqkvplane >= 0 &&
                  (dqkvplane % 4) == 0);
   float* dqkv = dqkvplane ? nullptr : static_cast<float*>(dqkvv);
   unsigned short* dqkvp = dqkvplane ? static_cast<unsigned short*>(dqkvv) : nullptr;
-  if (dH > AD || dH < 4 || (dH % 4) != 0 || L > AL || L < 1) return CXRK_ERR_UNSUPPORTED;
+  if (dH > AD || dH < 4 || (dH % 4) != 0 || L > ALONG || L < 1) return CXRK_ERR_UNSUPPORTED;
   const int ALD = dH + 4;
+  if (L > AL) {
+    if (ws == nullptr || ws_bytes < cxrk_attn_bwd_ws_bytes(B, L, nH, dH)) return CXRK_ERR_WS;
+    const float scale = 1.0f / sqrtf((float)dH);
+    const size_t shq = (size_t)((TQ + 2 * TK) * ALD + TQ * (TK + 1)) * sizeof(float);
+    const size_t shk = (size_t)(2 * TQ * ALD + 2 * TQ * (TK + 1)) * sizeof(float);
+    hipLaunchKernelGGL(attn_bwd_long_q_kernel, dim3((unsigned)(B * nH * ceil_div(L, TQ))), dim3(256), shq, stream, qkv, probs, dctx, L, nH,
+                       dH, scale, ws, dqkv, dqkvp, dqkvplane);
+    CXRK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_long_kv_kernel, dim3((unsigned)(B * nH * ceil_div(L, TK))), dim3(256), shk, stream, qkv, probs, ws, dctx, L,
+                       nH, dH, dqkv, dqkvp, dqkvplane);
+    CXRK_LAUNCH_CHECK();
+    return CXRK_OK;
+  }
   const size_t sh = (size_t)(4 * L * ALD + 2 * L * (L + 1)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -589,4 +852,3 @@ extern "C" int cxrk_attn_bwd(const float* qkv, const float* probs, const float* 
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
 }
-

@@ -252,15 +252,35 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const EpiPara
 #ifndef CXRK_GN
 #define CXRK_GN 8   // 0 = one chunk = plain M-panel-major order; 8: +3..7 % on the BERT GEMMs (N = 2304 / 3072) over 0
 #endif
-__device__ __forceinline__ void tile_coords(int nMt, int nNt, int& mt, int& nt) {
-  const int nwg = nMt * nNt;
-  const int b = blockIdx.x;
-  const int xcd = b & 7, idx = b >> 3;
-  const int qq = nwg >> 3, rr = nwg & 7;
-  const int wgid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+// Split-K launches (nz > 1 slabs): the grid is ONE list of nz * nMt * nNt workgroups, slab-major, and the XCD remap runs over the
+// whole list, so an XCD owns ~1/8 of it = whole slabs (or a contiguous run of tiles of one slab).  All tiles of a slab read the
+// same K-range of both operands: kept on one XCD, that range is fetched into ONE L2 instead of all eight.  (Round 2 remapped
+// inside each slab only — every XCD then held tiles of every slab, and the weight-gradient launches moved 2-3x their algorithmic
+// bytes through the fabric: profiles/r02_z_pmc_hbm_traffic.txt.)
+#ifndef CXRK_SLAB_MAJOR
+#define CXRK_SLAB_MAJOR 1   // 0 = round 2's order (tile list remapped per slab, slabs interleaved over the XCDs), for A/B measurements
+#endif
+__device__ __forceinline__ void tile_coords(int nMt, int nNt, int nz, int& mt, int& nt, int& z) {
+  const int per = nMt * nNt;
+  int wgid;
+  if (CXRK_SLAB_MAJOR || nz == 1) {
+    const int nwg = per * nz;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, idx = b >> 3;
+    const int qq = nwg >> 3, rr = nwg & 7;
+    const int w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    z = w / per;
+    wgid = w - z * per;
+  } else {
+    z = blockIdx.x / per;
+    const int b = blockIdx.x - z * per;
+    const int xcd = b & 7, idx = b >> 3;
+    const int qq = per >> 3, rr = per & 7;
+    wgid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+  }
   if (CXRK_GN <= 0 || nNt <= CXRK_GN) { mt = wgid / nNt; nt = wgid - mt * nNt; return; }
-  const int per = nMt * CXRK_GN;            // tiles of a full chunk
-  const int c = wgid / per, rem = wgid - c * per;
+  const int per_c = nMt * CXRK_GN;          // tiles of a full chunk
+  const int c = wgid / per_c, rem = wgid - c * per_c;
   const int width = min(CXRK_GN, nNt - c * CXRK_GN);
   mt = rem / width;                         // the last (narrower) chunk still holds nMt * width tiles
   nt = c * CXRK_GN + (rem - mt * width);
@@ -271,7 +291,7 @@ __device__ __forceinline__ void tile_coords(int nMt, int nNt, int& mt, int& nt) 
 #endif
 template <class LA, class LB, int WM, int WN>
 __global__ __launch_bounds__(NTHREADS, CXRK_OCC) void gemm_f32_kernel(typename LA::P pa, typename LB::P pb, EpiParams ep,
-                                                            int M, int N, int K, int nMt, int nNt, int kchunk) {
+                                                            int M, int N, int K, int nMt, int nNt, int nZ, int kchunk) {
   constexpr int BM = WM * 64, BN = WN * 64;
   constexpr int LDA = LA::LD, LDB = LB::LD;
   constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
@@ -289,10 +309,9 @@ __global__ __launch_bounds__(NTHREADS, CXRK_OCC) void gemm_f32_kernel(typename L
   float* const As0 = smem;
   float* const Bs0 = smem + NBUF * ASZ;
 
-  int mt, nt;
-  tile_coords(nMt, nNt, mt, nt);
+  int mt, nt, z;
+  tile_coords(nMt, nNt, nZ, mt, nt, z);
   const int m0 = mt * BM, n0 = nt * BN;
-  const int z = blockIdx.y;
   const int kbeg = z * kchunk;
   const int kend = min(K, kbeg + kchunk);
 
@@ -371,7 +390,7 @@ __global__ __launch_bounds__(NTHREADS, CXRK_OCC) void gemm_f32_kernel(typename L
 // ---------------------------------------------------------------------------------------------------------------
 template <class LA, class LB, int WM, int WN>
 __global__ __launch_bounds__(NTHREADS, (WM == 2 && WN == 2) ? 3 : 2) void gemm_x3_kernel(typename LA::P pa, typename LB::P pb, EpiParams ep,
-                                                              int M, int N, int K, int nMt, int nNt, int kchunk) {
+                                                              int M, int N, int K, int nMt, int nNt, int nZ, int kchunk) {
   constexpr int BM = WM * 64, BN = WN * 64;
   constexpr int PLANE_A = LA::PLANE, PLANE_B = LB::PLANE;  // halfwords
   static_assert(2 * (PLANE_A + PLANE_B) * 2 >= 4 * 32 * 64 * 4, "operand LDS too small to stage the epilogue");
@@ -381,10 +400,9 @@ __global__ __launch_bounds__(NTHREADS, (WM == 2 && WN == 2) ? 3 : 2) void gemm_x
   unsigned short* const Bhi = Alo + PLANE_A;
   unsigned short* const Blo = Bhi + PLANE_B;
 
-  int mt, nt;
-  tile_coords(nMt, nNt, mt, nt);
+  int mt, nt, z;
+  tile_coords(nMt, nNt, nZ, mt, nt, z);
   const int m0 = mt * BM, n0 = nt * BN;
-  const int z = blockIdx.y;
   const int kbeg = z * kchunk;
   const int kend = min(K, kbeg + kchunk);
 
@@ -527,7 +545,7 @@ static int launch_gemm(const typename LA::P& pa, const typename LB::P& pb, const
   int kchunk = K;
   if (splitk > 1) { kchunk = ceil_div(ceil_div(K, splitk), BK) * BK; splitk = ceil_div(K, kchunk); }
   else splitk = 1;
-  dim3 grid((unsigned)(nMt * nNt), (unsigned)splitk, 1);
+  dim3 grid((unsigned)(nMt * nNt * splitk), 1, 1);
   EpiParams e = ep;
   if (!prep_epilogue(e, M, N, splitk)) return CXRK_ERR_ARG;
   // split-bf16 only where it pays and is well conditioned: small problems (adapters, heads: < 1 GFLOP) and launches the
@@ -537,11 +555,11 @@ static int launch_gemm(const typename LA::P& pa, const typename LB::P& pb, const
   const bool split = planes_in || (gemm_precision_mode() == 1 && !force_fp32 && 2.0 * M * N * (double)K >= 1073741824.0);
   if constexpr (planes_in) {
     static_assert(LA::FMT_PLANES && LB::FMT_PLANES, "both operands must share the storage format");
-    hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
+    hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, splitk, kchunk);
   } else if (split)
-    hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
+    hipLaunchKernelGGL((gemm_x3_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, splitk, kchunk);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
+    hipLaunchKernelGGL((gemm_f32_kernel<LA, LB, WM, WN>), grid, dim3(NTHREADS), 0, stream, pa, pb, e, M, N, K, nMt, nNt, splitk, kchunk);
   CXRK_LAUNCH_CHECK();
   return splitk;  // >= 1: number of slabs actually written
 }

@@ -508,14 +508,13 @@ struct PwNoIssue { __device__ __forceinline__ void operator()(int, unsigned char
 // of tile t+1 have landed" before "anyone reads `nx`".
 template <class CFG, class LA, class LB>
 __global__ __launch_bounds__(CFG::NT, CFG::WAVES_PER_SIMD) void gemm_pw_kernel(typename LA::P pa, typename LB::P pb, EpiParams ep, int M, int N,
-                                                                               int K, int nMt, int nNt, int kchunk) {
+                                                                               int K, int nMt, int nNt, int nZ, int kchunk) {
   constexpr int STAGE = CFG::STAGE, PA = CFG::PLANE_A, PB = CFG::PLANE_B, WTM = CFG::WTM;
   constexpr bool EARLY = CFG::DMA_EARLY;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
-  int mt, nt;
-  tile_coords(nMt, nNt, mt, nt);
+  int mt, nt, z;
+  tile_coords(nMt, nNt, nZ, mt, nt, z);
   const int m0 = mt * CFG::TM, n0 = nt * CFG::TN;
-  const int z = blockIdx.y;
   const int kbeg = z * kchunk;
   const int kend = min(K, kbeg + kchunk);
   const int tid = threadIdx.x;
@@ -524,8 +523,8 @@ __global__ __launch_bounds__(CFG::NT, CFG::WAVES_PER_SIMD) void gemm_pw_kernel(t
   const int wm = wave / CFG::WGN, wn = wave % CFG::WGN;
   const int arow = wm * (WTM * 32), bcol = wn * 64;
 
-#define PW_STAMP(i) do { if (ep.stamps && tid == 0) { ep.stamps[(blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
-                            if ((i) == 0 || (i) == 4) ep.stamps[(blockIdx.x + (long)gridDim.x * blockIdx.y) * 8 + 5 + (i) / 4] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define PW_STAMP(i) do { if (ep.stamps && tid == 0) { ep.stamps[(long)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+                            if ((i) == 0 || (i) == 4) ep.stamps[(long)blockIdx.x * 8 + 5 + (i) / 4] = __builtin_amdgcn_s_memrealtime(); } } while (0)
   PW_STAMP(0);
   LA la; LB lb;
   la.init(pa, m0, wave, lane);
@@ -629,10 +628,10 @@ static int launch_gemm_pw(const typename LA::P& pa, const typename LB::P& pb, co
   int kchunk = K;
   if (splitk > 1) { kchunk = ceil_div(ceil_div(K, splitk), BK) * BK; splitk = ceil_div(K, kchunk); }
   else splitk = 1;
-  dim3 grid((unsigned)(nMt * nNt), (unsigned)splitk, 1);
+  dim3 grid((unsigned)(nMt * nNt * splitk), 1, 1);
   EpiParams e = ep;
   if (!prep_epilogue(e, M, N, splitk) || !e.fast) return CXRK_ERR_ARG;
-  hipLaunchKernelGGL((gemm_pw_kernel<CFG, LA, LB>), grid, dim3(CFG::NT), 0, stream, pa, pb, e, M, N, K, nMt, nNt, kchunk);
+  hipLaunchKernelGGL((gemm_pw_kernel<CFG, LA, LB>), grid, dim3(CFG::NT), 0, stream, pa, pb, e, M, N, K, nMt, nNt, splitk, kchunk);
   CXRK_LAUNCH_CHECK();
   return splitk;
 }

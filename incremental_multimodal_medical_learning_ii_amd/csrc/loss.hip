@@ -139,23 +139,27 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(const float* __restrict__
 }
 
 // dx_i = sum_p dc[i][p] * (yhat_p - cos*xhat_i)/|x_i| ; dy partial[blk][p] = sum_{i in blk} dc * (xhat_i - cos*yhat_p)/|y_p|
+// One launch covers the prompt columns [p0, p0 + Pc) of the P (the LDS accumulators hold Pc x D per wave; the host walks P in
+// chunks that fit): cosv / dcos rows are P wide, y / ynorm are indexed by the global prompt, dy_part is [blocks][Pc][D], and a
+// launch with p0 > 0 adds its part of dx to what the earlier chunks wrote.
 __global__ __launch_bounds__(256) void pairwise_cosine_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                   const float* __restrict__ cosv, const float* __restrict__ dcos,
                                                                   const float* __restrict__ xnorm, const float* __restrict__ ynorm,
-                                                                  long B, int P, int D, int rows_per, float* __restrict__ dx,
-                                                                  float* __restrict__ dy_part, int Pg,
+                                                                  long B, int P, int p0, int Pc, int D, int rows_per,
+                                                                  float* __restrict__ dx, float* __restrict__ dy_part, int Pg,
                                                                   const int* __restrict__ argmax) {
-  extern __shared__ float sm[];  // [4 waves][P][D]
+  extern __shared__ float sm[];  // [4 waves][Pc][D]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float* mine = sm + (long)w * P * D;
-  for (int i = lane; i < P * D; i += 64) mine[i] = 0.f;
+  float* mine = sm + (long)w * Pc * D;
+  for (int i = lane; i < Pc * D; i += 64) mine[i] = 0.f;
   const long r0 = (long)blockIdx.x * rows_per, r1 = min(B, r0 + rows_per);
   for (long row = r0 + w; row < r1; row += 4) {
     float xh[NV], acc[NV];
     const float ixn = 1.0f / xnorm[row];
 #pragma unroll
     for (int i = 0; i < NV; ++i) { const int c = lane + i * 64; xh[i] = c < D ? x[row * D + c] * ixn : 0.f; acc[i] = 0.f; }
-    for (int p = 0; p < P; ++p) {
+    for (int pl = 0; pl < Pc; ++pl) {
+      const int p = p0 + pl;
       float dc;   // Pg > 0: dcos is [B, P / Pg], the gradient of the group maximum, routed to the winner only
       if (Pg > 0) { const long o = row * (P / Pg) + p / Pg; dc = argmax[o] == p % Pg ? dcos[o] : 0.f; }
       else dc = dcos[row * P + p];
@@ -167,18 +171,22 @@ __global__ __launch_bounds__(256) void pairwise_cosine_bwd_kernel(const float* _
         if (c < D) {
           const float yh = y[(long)p * D + c] * iyn;
           acc[i] += dc * (yh - cs * xh[i]);
-          mine[p * D + c] += dc * (xh[i] - cs * yh) * iyn;
+          mine[pl * D + c] += dc * (xh[i] - cs * yh) * iyn;
         }
       }
     }
     if (dx) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) { const int c = lane + i * 64; if (c < D) dx[row * D + c] = acc[i] * ixn; }
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane + i * 64;
+        if (c < D) dx[row * D + c] = (p0 > 0 ? dx[row * D + c] : 0.f) + acc[i] * ixn;
+      }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < P * D; i += 256)
-    dy_part[(long)blockIdx.x * P * D + i] = (sm[i] + sm[(long)P * D + i]) + (sm[2L * P * D + i] + sm[3L * P * D + i]);
+  const long n = (long)Pc * D;
+  for (int i = threadIdx.x; i < n; i += 256)
+    dy_part[(long)blockIdx.x * n + i] = (sm[i] + sm[n + i]) + (sm[2 * n + i] + sm[3 * n + i]);
 }
 __global__ void partial_reduce_kernel(const float* __restrict__ part, int nparts, long n, float* __restrict__ out, int accumulate) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -339,20 +347,25 @@ static int cosine_bwd(const float* x, const float* y, const float* cosv, const f
                       int P, int D, float* dx, float* dy, int accumulate_dy, float* ws, size_t ws_bytes, int Pg, const int* argmax,
                       hipStream_t stream) {
   CXRK_CHECK_ARG(x && y && cosv && dcos && xnorm && ynorm && dy && B > 0 && P > 0 && D > 0 && D <= 64 * NV);
-  const size_t sh = (size_t)4 * P * D * sizeof(float);   // one [P][D] accumulator per wave
-  if (sh > 128 * 1024) return CXRK_ERR_UNSUPPORTED;
-  if (sh > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(pairwise_cosine_bwd_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess) return CXRK_ERR_LAUNCH;
+  // one [Pc][D] accumulator per wave in LDS: P is walked in chunks of at most 64 KiB / (4 waves x D x 4 B) prompts (32 at D = 128;
+  // NEW_PROMPTS with positive-only logits stacks 5 classes x 2 x 10 = 100 prompt rows into one call, Trainer.py:1691-1693)
+  int pc_max = (int)((64 * 1024) / ((size_t)4 * D * sizeof(float)));
+  if (pc_max < 1) return CXRK_ERR_UNSUPPORTED;
   int nb = cos_bwd_blocks(B);
   if (ws == nullptr || ws_bytes < (size_t)nb * P * D * sizeof(float)) return CXRK_ERR_WS;
   const int rows_per = (int)((B + nb - 1) / nb);
   nb = (int)((B + rows_per - 1) / rows_per);
-  hipLaunchKernelGGL(pairwise_cosine_bwd_kernel, dim3(nb), dim3(256), sh, stream, x, y, cosv, dcos, xnorm, ynorm, B, P, D,
-                     rows_per, dx, ws, Pg, argmax);
-  CXRK_LAUNCH_CHECK();
-  const long n = (long)P * D;
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ws, nb, n, dy, accumulate_dy);
-  CXRK_LAUNCH_CHECK();
+  for (int p0 = 0; p0 < P; p0 += pc_max) {
+    const int Pc = P - p0 < pc_max ? P - p0 : pc_max;
+    const size_t sh = (size_t)4 * Pc * D * sizeof(float);
+    hipLaunchKernelGGL(pairwise_cosine_bwd_kernel, dim3(nb), dim3(256), sh, stream, x, y, cosv, dcos, xnorm, ynorm, B, P, p0, Pc, D,
+                       rows_per, dx, ws, Pg, argmax);
+    CXRK_LAUNCH_CHECK();
+    const long n = (long)Pc * D;   // (the chunk's partials are consumed before the next launch overwrites them: same stream)
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ws, nb, n, dy + (long)p0 * D,
+                       accumulate_dy);
+    CXRK_LAUNCH_CHECK();
+  }
   return CXRK_OK;
 }
 

@@ -87,6 +87,10 @@ class ImageModel(nn.Module):
         self._specs, self._blocks = IE.resnet50_specs("encoder.encoder.", joint_feature_size)
         self._hot: Optional[Tuple[List[nn.Parameter], List[torch.Tensor]]] = None
         self._bn: Optional[List[nn.Module]] = None
+        # optional callable(stage): handed to every grad-enabled forward made while it is set and called by THAT forward's backward
+        # as the gradients of "head" (projector + layer4), "layer3", "layer2", "stem" (layer1 + stem) become complete
+        # (image_encoder._backward); set and cleared by the data-parallel trainer per step
+        self.grad_ready_hook = None
         if pretrained_model_path is not None:
             if not isinstance(pretrained_model_path, (str, Path)):
                 raise TypeError(f"Expected a string or Path, got {type(pretrained_model_path)}")
@@ -142,7 +146,8 @@ class ImageModel(nn.Module):
         self._check_mode()
         self.prepare_()
         params, bufs = self._tensors()
-        meta = (self._specs, self._blocks, len(params), want_patch)
+        hook = self.grad_ready_hook if torch.is_grad_enabled() else None
+        meta = (self._specs, self._blocks, len(params), want_patch, hook)
         with torch.set_grad_enabled(torch.is_grad_enabled() and not self.freeze_encoder):
             emb, patch = IE.ImageEncodeFn.apply(x, meta, *params, *bufs)
         return emb, patch
@@ -159,6 +164,18 @@ class ImageModel(nn.Module):
         self._check_mode()
         params, bufs = self._tensors()
         return IE.project_patches(self._specs, params, bufs, patch_embeddings)
+
+    @torch.no_grad()
+    def calibrate_batchnorm_(self, x: torch.Tensor) -> "ImageModel":
+        """Replace every BatchNorm's running statistics by the statistics of its input over the batch `x` (one train-mode pass
+        with momentum 1, on the HIP kernels).  Not part of the reference's surface: it gives synthetic weights the matched
+        statistics a trained checkpoint has (bench.py)."""
+        if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"calibrate_batchnorm_: expected fp32 [B,3,H,W] images on the GPU, got {x.dtype} {tuple(x.shape)} on {x.device}")
+        self.prepare_()
+        params, bufs = self._tensors()
+        IE.calibrate_batchnorm_(self._specs, self._blocks, params, bufs, x)
+        return self
 
     @torch.no_grad()
     def forward_stages(self, x: torch.Tensor):

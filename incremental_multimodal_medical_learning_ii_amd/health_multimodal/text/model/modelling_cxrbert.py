@@ -67,6 +67,9 @@ class CXRBertModel(BertForMaskedLM):
         else:  # transformers 4.17 spelling used by the reference (:68)
             self.init_weights()
         self._hot: Optional[List[nn.Parameter]] = None
+        # optional callable(tag): handed to every grad-enabled encode call made while it is set and called by THAT call's backward
+        # when its parameter gradients are complete (text_encoder.encode); set and cleared by the data-parallel trainer per step
+        self.grad_ready_hook = None
 
     # ------------------------------------------------------------------ parameter plumbing
     def _hot_params(self) -> List[nn.Parameter]:
@@ -102,7 +105,8 @@ class CXRBertModel(BertForMaskedLM):
         if getattr(cfg, "hidden_act", "gelu") != "gelu":
             raise NotImplementedError(f"hidden_act={cfg.hidden_act!r}: only erf-GELU (CXR-BERT) is implemented")
         return TE.encode(self._hot_params(), input_ids, attention_mask, cfg.num_hidden_layers,
-                         cfg.num_attention_heads, cfg.layer_norm_eps, cls_only, want_last)
+                         cfg.num_attention_heads, cfg.layer_norm_eps, cls_only, want_last,
+                         on_grads_ready=self.grad_ready_hook if torch.is_grad_enabled() else None)
 
     @torch.no_grad()
     def _mlm_logits(self, last_hidden: torch.Tensor) -> torch.Tensor:

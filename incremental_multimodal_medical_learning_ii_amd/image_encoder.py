@@ -249,7 +249,23 @@ def _dgrad(i, s, fold, dy, residual, relu, N, H, W, pl, want_sums):
     return (dx, sums) if want_sums else dx
 
 
-def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatch: Optional[torch.Tensor], sink: GradSink):
+def stage_of_param(name: str) -> str:
+    """Stage tag of an image-encoder parameter, in the order the backward completes them: "head" (projector + layer4),
+    "layer3", "layer2", "stem" (layer1 + the stem)."""
+    if name.startswith("projector.") or ".layer4." in name:
+        return "head"
+    if ".layer3." in name:
+        return "layer3"
+    if ".layer2." in name:
+        return "layer2"
+    return "stem"
+
+
+def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatch: Optional[torch.Tensor], sink: GradSink,
+              on_grads_ready=None):
+    """`on_grads_ready(tag)` (optional) is called on the current stream when every parameter gradient of a stage has been written
+    in place: "head" after the projector and layer4, "layer3", "layer2", and "stem" (layer1 + stem) at the end — only while no
+    gradient of the stage had to be returned to autograd as a fresh tensor."""
     fold, x0, stem, idx, pooled, binfo, last, pj1, mp, w3p, (N, H, W, Hs, Ws, h, w), pl = state
     ns = len(specs)
     ip = ns - 1
@@ -320,6 +336,11 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
             g, gs = _dgrad(blk["c1"], s1, fold, d1, res, None, N, hi, wi, pl, False), None
         del d1, res
         binfo[bi] = None
+        if on_grads_ready is not None and blk["ds"] is not None and bi > 0:
+            # the first block of layer4 / layer3 / layer2 is done: every gradient from its first unit onwards is complete
+            stage = {LAYERS[0] + LAYERS[1] + LAYERS[2]: "head", LAYERS[0] + LAYERS[1]: "layer3", LAYERS[0]: "layer2"}[bi]
+            if all(r is None for r in sink.ret[3 * blk["c1"]:]):
+                on_grads_ready(stage)
     if pl:
         ds = K.maxpool_bwd_pl(g, idx, pooled, Hs, Ws)
     else:
@@ -328,6 +349,8 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
         _debug["ds"], _debug["x0"] = ds, x0
     sum_s = K.colsum(ds.view(-1, ds.shape[-1]), torch.empty(ds.shape[-1], dtype=torch.float32, device=dev))
     _unit_params_bwd(0, specs[0], fold, p, bufs, x0, ds, sum_s, N, H, W, sink, False)   # fp32 operands (the image), split on the fly in split_bf16 mode
+    if on_grads_ready is not None and all(r is None for r in sink.ret):
+        on_grads_ready("stem")
     return sink.ret
 
 
@@ -371,6 +394,111 @@ def relu_decisions(state) -> List[torch.Tensor]:
     return out
 
 
+def _pack_bits(a: torch.Tensor) -> torch.Tensor:
+    """bool [rows, C] (device) -> the ReLU bit-mask layout of the epilogues: uint8 [rows, C/8], bit c % 8 of byte c / 8."""
+    rows, C = a.shape
+    w = 1 << torch.arange(8, device=a.device, dtype=torch.int32)
+    return (a.view(rows, C // 8, 8).to(torch.int32) * w).sum(-1).to(torch.uint8)
+
+
+def device_decisions(state) -> dict:
+    """Every 0/1 decision of a saved forward pass, kept ON THE DEVICE in the layout the planes backward reads: per bottleneck the
+    three ReLU bit masks, the projector's, the max-pool winners and the stem's ReLU decision at the winning input.  Works on the
+    state of either storage mode; `impose_decisions_` writes such a set into a planes-mode state.  Test / bench instrumentation
+    (full-size cross-precision gradient check): two correct forwards differ in the last bits, so a few 1e-5 of the decisions
+    differ, and a gradient is only comparable under equal decisions."""
+    fold, x0, stem, idx, pooled, binfo, cur, pj1, mp, w3p, dims, pl = state
+    if pl:
+        blocks = [(b[8], b[9], b[10]) for b in binfo]
+        proj = mp
+        stem_pos = pooled.t[0].float() > 0
+    else:
+        blocks = [tuple(_pack_bits((b[k] > 0).view(-1, b[k].shape[-1])) for k in (1, 2, 3)) for b in binfo]
+        proj = _pack_bits((pj1 > 0).view(-1, pj1.shape[-1]))
+        stem_pos = pooled > 0
+    return {"blocks": [tuple(m.clone() for m in t) for t in blocks], "proj": proj.clone(), "pool_taps": idx.clone(), "stem_pos": stem_pos}
+
+
+def count_decision_differences(a: dict, b: dict) -> dict:
+    """How many decisions differ between two `device_decisions` sets (population counts of the XOR-ed masks)."""
+    def bits(x, y):
+        d = (x ^ y).to(torch.int32)
+        n = 0
+        for k in range(8):
+            n += int(((d >> k) & 1).sum())
+        return n
+    relu = sum(bits(x, y) for ta, tb in zip(a["blocks"], b["blocks"]) for x, y in zip(ta, tb)) + bits(a["proj"], b["proj"])
+    total = sum(x.numel() * 8 for ta in a["blocks"] for x in ta) + a["proj"].numel() * 8
+    return {"relu": relu + int((a["stem_pos"] != b["stem_pos"]).sum()), "relu_total": total + a["stem_pos"].numel(),
+            "pool_taps": int((a["pool_taps"] != b["pool_taps"]).sum()), "pool_total": a["pool_taps"].numel()}
+
+
+def impose_decisions_(node, dec: dict) -> None:
+    """Overwrite the decisions a planes-mode forward saved for its backward (`node` = the `grad_fn` of its output) with `dec`:
+    the backward then differentiates the function the OTHER forward selected.  The stem's ReLU decision is read by the max-pool
+    backward from the sign of the pooled activation's hi plane; it gets a stand-in tensor that carries the imposed signs, the
+    pooled activation itself (the weight-gradient operand of layer1.0) stays untouched."""
+    fold, x0, stem, idx, pooled, binfo, cur, pj1, mp, w3p, dims, pl = node.state
+    if not pl:
+        raise RuntimeError("impose_decisions_: only the planes (split_bf16) backward reads stored decisions")
+    for b, t in zip(binfo, dec["blocks"]):
+        for m, src in zip((b[8], b[9], b[10]), t):
+            m.copy_(src)
+    mp.copy_(dec["proj"])
+    idx.copy_(dec["pool_taps"])
+    sign = Planes(torch.zeros_like(pooled.t))
+    sign.t[0].copy_(dec["stem_pos"].to(torch.bfloat16))
+    node.state = (fold, x0, stem, idx, sign, binfo, cur, pj1, mp, w3p, dims, pl)
+
+
+@torch.no_grad()
+def calibrate_batchnorm_(specs, blocks, params, bufs, x: torch.Tensor) -> None:
+    """Set the running statistics of every BatchNorm of the encoder to the statistics of its input over the batch `x` (what one
+    train-mode pass with momentum 1 would leave behind; `torch.nn.BatchNorm2d` semantics: unbiased variance), unit by unit in
+    execution order on the encoder's own kernels: the raw convolution output of a unit is obtained by folding an identity
+    BatchNorm, then the unit is re-run with its new statistics to feed the next one.  Used to give SYNTHETIC weights the property
+    every trained checkpoint has — statistics that match the activations — without which a random ResNet-50 in eval mode maps all
+    images to nearly the same embedding (bench.py; the reference only ever loads trained BioViL weights, model.py:117-118)."""
+    import math
+    N, C, H, W = x.shape
+    dev = x.device
+    pl = _planes_mode()
+    fold = _Fold(specs, dev, pl)
+    p = [t.detach() for t in params]
+    b = [t.detach() for t in bufs]
+    k = math.sqrt(1.0 + BN_EPS)          # the identity fold scales by rsqrt(1 + eps)
+
+    def fold_unit(i, s, gamma, beta, mean, var):
+        args = (_filter_rsc(p[3 * i]), gamma, beta, mean, var, BN_EPS, s.cout, s.k * s.k, s.cin, s.cpad)
+        fn = K.bn_fold_pl if (pl and i > 0) else K.bn_fold
+        fn(*args, fold.ws(i, s), fold.scale(i, s), fold.shift(i, s), fold.rstd(i, s))
+
+    def unit(i, xin, residual, relu, h, w, want_mask=True):
+        s = specs[i]
+        one, zero = torch.ones(s.cout, device=dev), torch.zeros(s.cout, device=dev)
+        fold_unit(i, s, one, zero, zero, one)
+        raw, _ = _conv(i, s, fold, xin, None, False, N, h, w, pl, want_mask=False)
+        r = (raw.float() if pl else raw).reshape(-1, s.cout)
+        var, mean = torch.var_mean(r.double(), dim=0, unbiased=True)
+        b[2 * i].copy_((mean * k).float())
+        b[2 * i + 1].copy_((var * k * k).float().clamp_min(1e-12))
+        del raw, r
+        fold_unit(i, s, p[3 * i + 1], p[3 * i + 2], b[2 * i], b[2 * i + 1])
+        return _conv(i, s, fold, xin, residual, relu, N, h, w, pl, want_mask=want_mask)[0]
+
+    stem = unit(0, K.nchw_to_nhwc(x, 4), None, True, H, W, want_mask=False)
+    cur = (K.maxpool_fwd_pl(stem) if pl else K.maxpool_fwd(stem))[0]
+    del stem
+    h, w = cur.shape[1], cur.shape[2]
+    for blk in blocks:
+        o1 = unit(blk["c1"], cur, None, True, h, w)
+        o2 = unit(blk["c2"], o1, None, True, h, w)
+        h2, w2 = o2.shape[1], o2.shape[2]
+        idt = unit(blk["ds"], cur, None, False, h, w) if blk["ds"] is not None else cur
+        cur, h, w = unit(blk["c3"], o2, idt, True, h2, w2), h2, w2
+    unit(len(specs) - 1, cur, None, True, h, w)
+
+
 _capture: Optional[list] = None
 _debug: Optional[dict] = None      # diagnostics (scripts/exp_grad_err.py): set to a dict to receive the stem's gradient tensors
 
@@ -396,7 +524,7 @@ class ImageEncodeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, meta, *tensors):
-        specs, blocks, n_params, want_patch = meta
+        specs, blocks, n_params, want_patch = meta[:4]
         ctx.set_materialize_grads(False)
         params, bufs = tensors[:n_params], tensors[n_params:]
         save = any(t.requires_grad for t in params)
@@ -413,11 +541,12 @@ class ImageEncodeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, demb, dpatch):
-        specs, blocks, n_params, want_patch = ctx.meta
+        specs, blocks, n_params, want_patch = ctx.meta[:4]
+        hook = ctx.meta[4] if len(ctx.meta) > 4 else None    # per-call `on_grads_ready` (ImageModel.grad_ready_hook at forward time)
         if dpatch is not None and dpatch.numel() == 0:
             dpatch = None
         sink = GradSink(ctx.params)
-        grads = _backward(specs, blocks, ctx.p, ctx.b, ctx.state, demb, dpatch, sink)
+        grads = _backward(specs, blocks, ctx.p, ctx.b, ctx.state, demb, dpatch, sink, hook)
         ctx.state = None
         return (None, None) + tuple(grads) + (None,) * len(ctx.b)
 

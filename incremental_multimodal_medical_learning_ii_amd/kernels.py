@@ -123,8 +123,8 @@ def _pl2d(t: Planes, name: str):
 class LaunchProfiler:
     """Optional per-launch timing of the MFMA GEMM family with HIP events recorded on the launch stream
     (bench.py's `roofline` object).  Off by default; when on, every GEMM / implicit-GEMM launch is bracketed by two
-    events and tagged with its kernel instantiation, its algorithmic FLOPs (2*M*N*K) and its algorithmic HBM bytes (every
-    operand and side input read once, every output written once)."""
+    events and tagged with its kernel instantiation (the name rocprofv3 reports, scripts/pmc_summary_key.py), its algorithmic
+    FLOPs (2*M*N*K) and its algorithmic HBM bytes (every operand and side input read once, every output written once)."""
 
     def __init__(self):
         self.on = False
@@ -136,20 +136,21 @@ class LaunchProfiler:
     def stop(self):
         self.on = False
 
-    def bracket(self, key: str, flops: float, nbytes: float = 0.0):
+    def bracket(self, key: str, flops: float, nbytes: float = 0.0, sub: int = 1):
+        """`sub`: kernel launches inside the bracket (a stride-2 data gradient is one launch per output-parity class)"""
         if not self.on:
             return None
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        self.rows.append((key, flops, nbytes, a, b))
+        self.rows.append((key, flops, nbytes, a, b, sub))
         return b
 
     def summary(self):
         """{kernel: {"launches", "flops", "bytes", "ms"}} — call after torch.cuda.synchronize()."""
         out = {}
-        for key, flops, nbytes, a, b in self.rows:
+        for key, flops, nbytes, a, b, sub in self.rows:
             d = out.setdefault(key, {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0})
-            d["launches"] += 1
+            d["launches"] += sub
             d["flops"] += flops
             d["bytes"] += nbytes
             d["ms"] += a.elapsed_time(b)
@@ -448,6 +449,16 @@ def _conv_out(H, W, R, S, stride, pad):
     return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
 
 
+def _dgrad_label(N, H, W, Ko, R, S, stride):
+    """(A loader, B loader, GEMM rows, GEMM K, kernel launches) of a data gradient as the library runs it: stride 1 = one launch over
+    all pixels; stride 2 = one launch per output-parity class that a tap reaches (4 for a 3x3, 1 for a 1x1), each over a quarter of the
+    pixels with that class's taps (csrc/conv_dgrad.hip) — a different kernel instantiation, labelled as such."""
+    if stride == 1:
+        return "ConvDgradKC", "ConvFilterMC", N * H * W, R * S * Ko, 1
+    classes = 4 if R > 1 else 1
+    return "ConvDgradS2KC", "ConvFilterS2MC", N * ((H + 1) // 2) * ((W + 1) // 2), Ko * max(1, (R * S) // 4), classes
+
+
 def conv_bwd_data(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R, S, stride, pad, sums=None):
     """dx = (relu_src > 0) * (conv^T(dy, w_scaled) + residual); `sums` ([C], optional) receives the column sums of dx (the BN beta
     gradient of the unit that produced relu_src), reduced in the same epilogue."""
@@ -457,9 +468,9 @@ def conv_bwd_data(dy, w_scaled, residual, relu_src, dx, N, H, W, C, Ko, R, S, st
     if profiler.on:  # algorithmic FLOPs of a data gradient = those of the forward conv (stride-2 zero taps are waste)
         Ho, Wo = _conv_out(H, W, R, S, stride, pad)
         fl = 2.0 * N * Ho * Wo * Ko * R * S * C
-        ev = profiler.bracket(_label("ConvDgradKC", "ConvFilterMC", "4,1" if C <= 64 else "2,2", N * H * W, C, R * S * Ko, 1,
-                                     2 if stride == 1 else 3), fl,
-                              4.0 * (N * Ho * Wo * Ko + Ko * R * S * C + N * H * W * C * (1 + (residual is not None) + (relu_src is not None))))
+        la, lb, Ml, Kl, sub = _dgrad_label(N, H, W, Ko, R, S, stride)
+        ev = profiler.bracket(_label(la, lb, "4,1" if C <= 64 else "2,2", Ml, C, Kl, 1, 2), fl,
+                              4.0 * (N * Ho * Wo * Ko + Ko * R * S * C + N * H * W * C * (1 + (residual is not None) + (relu_src is not None))), sub)
     rc = lib.cxrk_conv_bn_act_bwd_data(_p(_chk(dy, "conv.dy")), _p(w_scaled), _p(residual), _p(relu_src), _p(dx), N, H,
                                        W, C, Ko, R, S, stride, pad, _p(sums), _p(ws), ws.numel() * 4 if ws is not None else 0, _stream())
     if ev is not None:
@@ -535,10 +546,10 @@ def conv_bwd_data_pl(dy: Planes, w_scaled: Planes, residual: Optional[Planes], m
     if profiler.on:
         Ho, Wo = _conv_out(H, W, R, S, stride, pad)
         fl = 2.0 * N * Ho * Wo * Ko * R * S * C
-        ev = profiler.bracket(_label("ConvDgradKC", "ConvFilterMC", "4,1" if C <= 64 else "2,2", N * H * W, C, R * S * Ko, 1,
-                                     2 if stride == 1 else 3, planes=True), fl,
+        la, lb, Ml, Kl, sub = _dgrad_label(N, H, W, Ko, R, S, stride)
+        ev = profiler.bracket(_label(la, lb, "4,1" if C <= 64 else "2,2", Ml, C, Kl, 1, 2, planes=True), fl,
                               4.0 * (N * Ho * Wo * Ko + Ko * R * S * C + N * H * W * C * (1 + (residual is not None)))
-                              + (N * H * W * C / 8.0 if maskin is not None else 0.0))
+                              + (N * H * W * C / 8.0 if maskin is not None else 0.0), sub)
     rc = lib.cxrk_conv_bn_act_bwd_data_pl(dy.ptr(), dy.plane, w_scaled.ptr(), w_scaled.plane, residual.ptr() if residual is not None else None,
                                           residual.plane if residual is not None else 0, _p(maskin), dx.ptr(), dx.plane, N, H, W, C, Ko, R, S,
                                           stride, pad, _p(sums), _p(ws), ws.numel() * 4 if ws is not None else 0, _stream())
@@ -730,8 +741,10 @@ def attn_fwd(qkv, mask, B, L, nH, dH, save_probs: bool = True, out_planes: bool 
 def attn_bwd(qkv, probs, dctx, B, L, nH, dH, out_planes: bool = False):
     lib = _lib.load()
     dqkv, dp, dpl = _new_out(qkv.shape[0], qkv.shape[1], qkv.device, out_planes)
-    check(lib.cxrk_attn_bwd(_p(qkv), _p(probs), _p(_chk(dctx, "attn.dctx")), B, L, nH, dH, dp, dpl, _stream()),
-          "cxrk_attn_bwd")
+    wsb = lib.cxrk_attn_bwd_ws_bytes(B, L, nH, dH)        # the dS matrix of the tiled form (L > 64); 0 otherwise
+    ws = workspace(wsb, qkv.device) if wsb else None
+    check(lib.cxrk_attn_bwd(_p(qkv), _p(probs), _p(_chk(dctx, "attn.dctx")), B, L, nH, dH, dp, dpl, _p(ws),
+                            ws.numel() * 4 if ws is not None else 0, _stream()), f"cxrk_attn_bwd(B={B},L={L},nH={nH},dH={dH})")
     return dqkv
 
 

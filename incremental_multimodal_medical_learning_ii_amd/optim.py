@@ -97,14 +97,19 @@ class _FlatOptimizer:
         step = max(1, bucket_bytes // 4)
         return [dist.all_reduce(self.flat_g[o:min(hi, o + step)], group=group, async_op=True) for o in range(lo, hi, step)]
 
-    def all_reduce_grads(self, group=None, bucket_bytes: int = 256 << 20, average: bool = False, skip: Optional[tuple] = None,
-                         pending: Optional[list] = None) -> None:
-        """Sum (or average) the flat gradient buffer over the data-parallel group in large contiguous buckets.  `skip` = an
-        element range already being reduced by `all_reduce_span` (its handles in `pending`)."""
+    def all_reduce_grads(self, group=None, bucket_bytes: int = 256 << 20, average: bool = False, skip=None,
+                         pending: Optional[list] = None, pre_scale: Optional[float] = None) -> None:
+        """Sum (or average) the flat gradient buffer over the data-parallel group in large contiguous buckets.  `skip` = element
+        range(s) already being reduced by `all_reduce_span` (one (lo, hi) tuple or a list of them; their handles in `pending`).
+        `pre_scale`: multiply this rank's gradients by it before the sum (shards of unequal size: rows / global rows)."""
         import torch.distributed as dist
         self._sync_grads()
         n = self.flat_g.numel()
-        spans = [(0, n)] if skip is None else [(0, skip[0]), (skip[1], n)]
+        if pre_scale is not None:
+            if skip:
+                raise ValueError("all_reduce_grads: pre_scale cannot be combined with ranges that are already being reduced")
+            K.scale_mask(self.flat_g, alpha=float(pre_scale), out=self.flat_g)
+        spans = _complement(skip, n)
         works = list(pending or [])
         for lo, hi in spans:
             if hi > lo:
@@ -117,6 +122,23 @@ class _FlatOptimizer:
     @property
     def lr(self) -> float:
         return float(self.param_groups[0]["lr"])
+
+
+def _complement(skip, n: int) -> list:
+    """[0, n) minus the (lo, hi) range(s) in `skip` (which must not overlap), as a sorted list of ranges."""
+    if not skip:
+        return [(0, n)]
+    ranges = sorted([tuple(skip)] if isinstance(skip[0], int) else [tuple(r) for r in skip])
+    out, pos = [], 0
+    for lo, hi in ranges:
+        if lo < pos or hi > n or hi < lo:
+            raise ValueError(f"all_reduce_grads: skip ranges {ranges} overlap or leave the buffer of {n} elements")
+        if lo > pos:
+            out.append((pos, lo))
+        pos = hi
+    if pos < n:
+        out.append((pos, n))
+    return out
 
 
 def _dense(p: torch.Tensor) -> bool:

@@ -307,19 +307,14 @@ def _backward(p: Sequence[torch.Tensor], ids: torch.Tensor, n_layers: int, n_hea
         K.colsum(demb, dtyp[0], accumulate=acc)
 
 
-# Called at the end of the encoder's backward, on the stream it ran on, when all its parameter gradients were written in place
-# (contrastive.JointContrastiveTrainer: start the gradient all-reduce of the text encoder while the image encoder is still in
-# its backward).  None = nothing to do.
-after_backward = None
-
-
 class CXRBertEncodeFn(torch.autograd.Function):
     """(ids, mask, cfg, cls_only, *params) -> (cls_projected_embedding [N,P], last_hidden_state [N,L,H], or [N,1,H] = its
     CLS rows when cls_only; an empty tensor when the caller does not want it)."""
 
     @staticmethod
-    def forward(ctx, ids, mask, n_layers, n_heads, eps, cls_only, want_last, *params):
+    def forward(ctx, ids, mask, n_layers, n_heads, eps, cls_only, want_last, on_grads_ready, *params):
         ctx.set_materialize_grads(False)
+        ctx.on_grads_ready = on_grads_ready
         save = any(t.requires_grad for t in params)
         p = [t.detach() for t in params]
         proj, last, state = _forward(p, ids, mask, n_layers, n_heads, eps, save, cls_only)
@@ -347,18 +342,22 @@ class CXRBertEncodeFn(torch.autograd.Function):
         ctx.state = None
         ctx.last = None
         res = sink.result()
-        hook = after_backward
+        hook = ctx.on_grads_ready
         if hook is not None and all(r is None for r in res):
-            hook()   # every gradient of this encoder already sits in its `.grad` view: the data-parallel step starts reducing them now
-        return (None, None, None, None, None, None, None) + res
+            hook("text")   # every gradient of this encoder already sits in its `.grad` view: the data-parallel step starts reducing them now
+        return (None, None, None, None, None, None, None, None) + res
 
 
 def encode(params: Sequence[torch.Tensor], ids: torch.Tensor, mask: Optional[torch.Tensor], n_layers: int,
-           n_heads: int, eps: float = 1e-12, cls_only: bool = False, want_last: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+           n_heads: int, eps: float = 1e-12, cls_only: bool = False, want_last: bool = True,
+           on_grads_ready=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`on_grads_ready(tag)`: optional callable bound to THIS call (it travels on the autograd node, not in a module global); the
+    backward calls it with "text" on the stream it runs on once every parameter gradient of the call has been written in place
+    (`gradsink`).  contrastive.JointContrastiveTrainer starts the encoder's gradient all-reduce from it."""
     if ids.dtype != torch.int64:
         ids = ids.to(torch.int64)
     if mask is not None and mask.dtype != torch.int64:
         mask = mask.to(torch.int64)
     ids = ids.contiguous()
     mask = mask.contiguous() if mask is not None else None
-    return CXRBertEncodeFn.apply(ids, mask, n_layers, n_heads, eps, bool(cls_only), bool(want_last), *params)
+    return CXRBertEncodeFn.apply(ids, mask, n_layers, n_heads, eps, bool(cls_only), bool(want_last), on_grads_ready, *params)

@@ -9,18 +9,9 @@ if args and args[0] == "--json":
     out_json, args = args[1], args[2:]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(collections.Counter)
 
-def key(k):
-    m = re.search(r"gemm_pw_kernel<cxrk::PwCfg<(\d), (\d), (\d)>, cxrk::(\w+)<[^>]*>, cxrk::(\w+)<[^>]*>\s*>", k)
-    if m:
-        cfg = {"244": "Pw256", "222": "Pw128", "412": "Pw256x64", "142": "Pw64x256"}.get(m.group(1) + m.group(2) + m.group(3), "Pw?")
-        return f"gemm_pw_kernel<{cfg},{m.group(4)},{m.group(5)}>"
-    m = re.search(r"(gemm_x3_kernel)<cxrk::(\w+)<\d+, cxrk::PL[^>]*>, cxrk::(\w+)<\d+, cxrk::PL[^>]*>\s*, (\d), (\d)\s*>", k)
-    if m:
-        return f"{m.group(1)}<{m.group(2)}<PL>,{m.group(3)}<PL>,{m.group(4)},{m.group(5)}>"
-    m = re.search(r"(gemm_\w+_kernel)<cxrk::(\w+)<[^>]*>, cxrk::(\w+)<[^>]*>\s*(?:, (\d), (\d))?\s*>", k)
-    if m:
-        return f"{m.group(1)}<{m.group(2)},{m.group(3)}" + (f",{m.group(4)},{m.group(5)}>" if m.group(4) else ">")
-    return re.sub(r"\(.*", "", k).replace("(anonymous namespace)::", "").replace("void ", "")[:50]
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_summary_key import key  # noqa: E402
 
 for path in args:
     for r in csv.DictReader(open(path)):
@@ -40,4 +31,4 @@ if out_json:
                           "--steps 1 --warmup 1 --no-secondary --no-cpu-baseline --no-roofline",
                "correction": "gfx950: HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM section: FETCH_SIZE reports half "
                              "of wide coalesced reads)",
-               "round": 2, "precision": "split_bf16", "kernels": js}, open(out_json, "w"), indent=1)
+               "round": 3, "precision": "split_bf16", "kernels": js}, open(out_json, "w"), indent=1)

@@ -51,3 +51,77 @@ def scale_mask(x, mask_src=None, alpha_dev=None, alpha=1.0, out=None):
         return v
     out.copy_(v)
     return out
+
+
+# ---- the adapter (T-ref) step: what Trainer._train_step calls, for the 2-rank CPU rehearsal of its data-parallel form ----------
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+AUX_NONE, AUX_RELU_MASK, AUX_GELU_GRAD, AUX_MASK_BITS = 0, 1, 2, 3
+
+
+def linear_fwd(x, w, bias=None, act=0, residual=None, preact_out=None, out=None):
+    y = x @ w.T
+    if bias is not None:
+        y = y + bias
+    if act == ACT_RELU:
+        y = torch.relu(y)
+    return y
+
+
+def linear_bwd_data(dy, w, aux=None, auxmode=0, residual=None, out=None, accumulate=False):
+    dx = dy @ w
+    if auxmode == AUX_RELU_MASK:
+        dx = dx * (aux > 0)
+    return dx
+
+
+def linear_bwd_weight(dy, x, dw, accumulate=False):
+    g = dy.T @ x
+    dw.copy_(dw + g if accumulate else g)
+    return dw
+
+
+def colsum(x, out, alpha=1.0, accumulate=False):
+    s = alpha * x.sum(0)
+    out.copy_(out + s if accumulate else s)
+    return out
+
+
+def group_mean_fwd(x, G, n):
+    return x.reshape(G, n, -1).mean(1)
+
+
+def group_mean_bwd(dout, G, n):
+    return (dout / n).unsqueeze(1).expand(G, n, dout.shape[-1]).reshape(G * n, -1).contiguous()
+
+
+def pairwise_cosine_fwd(x, y):
+    xn, yn = x.norm(dim=1), y.norm(dim=1)
+    return (x / xn[:, None]) @ (y / yn[:, None]).T, xn, yn
+
+
+def pairwise_cosine_bwd(x, y, cosv, dcos, xn, yn, need_dx=True):
+    xh, yh = x / xn[:, None], y / yn[:, None]
+    dx = (dcos @ yh - (dcos * cosv).sum(1, keepdim=True) * xh) / xn[:, None]
+    dy = (dcos.T @ xh - (dcos * cosv).sum(0)[:, None] * yh) / yn[:, None]
+    return (dx if need_dx else None), dy
+
+
+def bce_posneg_fwd_bwd(cosv, labels, diff=True, need_grad=True):
+    B, C2 = cosv.shape
+    cp, cn = cosv[:, 0::2], cosv[:, 1::2]
+    z = cp - cn if diff else cp
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(z, labels)
+    dz = (torch.sigmoid(z) - labels) / z.numel()
+    dcos = torch.zeros_like(cosv)
+    dcos[:, 0::2] = dz
+    if diff:
+        dcos[:, 1::2] = -dz
+    return z, dcos, loss
+
+
+def adam_fused(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    gg = g * grad_scale
+    m.mul_(beta1).add_(gg, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+    mh, vh = m / (1 - beta1 ** step), v / (1 - beta2 ** step)
+    p.sub_(lr * mh / (vh.sqrt() + eps))

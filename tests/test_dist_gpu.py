@@ -63,6 +63,8 @@ def _worker(rank, world, port, out_dir, precision):
     sl = slice(rank * B, (rank + 1) * B)
     loss = tr.step(images[sl].to("cuda"), ids[sl].to("cuda"), mask[sl].to("cuda"))
     torch.cuda.synchronize()
+    # every range of the flat gradient buffer was reduced from inside the backward (text encoder + the image encoder's four stages)
+    assert sorted(tr.last_overlapped) == ["head", "layer2", "layer3", "stem", "text"], tr.last_overlapped
     sample, total = _probe(tr)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), loss=float(loss.item()), sample=sample, total=total)
     dist.barrier()

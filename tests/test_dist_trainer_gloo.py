@@ -1,0 +1,135 @@
+"""Data-parallel form of the reference's adapter step (`Trainer.train`, `Trainer.py:537-601`) on CPU: 2 processes, gloo backend,
+the kernel wrappers emulated by tests/cpu_kernels.py (what is checked is the orchestration in `Trainer._train_step`: every rank
+draws the same global batch, trains on its row shard, weights its gradient by shard size and all-reduces the flat buffer).  A
+2-rank run on a global batch of 9 rows (shards of 4 and 5) must reproduce the single-process update of the CPU oracle
+(`oracle/ref_step.adapter_step`).  Also: the gradient ranges the joint step reduces early tile the flat buffer exactly."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B, STEPS, LR = 9, 3, 1e-3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FrozenBert:
+    """stand-in for the frozen CXR-BERT engine: a fixed embedding per prompt string (hash-seeded), like the cached outputs"""
+    model = None
+
+    def to(self, device):
+        return self
+
+    def get_embeddings_from_prompt(self, prompts, normalize=False, verbose=False):
+        from incremental_multimodal_medical_learning_ii_amd import synthetic as syn
+        return torch.stack([torch.from_numpy(syn._normal("prompt::" + p, (128,))) for p in prompts])
+
+
+def _make_trainer(cpu_kernels):
+    import incremental_multimodal_medical_learning_ii_amd.Trainer as TR
+    from incremental_multimodal_medical_learning_ii_amd import functional as Fh
+    from incremental_multimodal_medical_learning_ii_amd import optim as cxr_optim
+    from incremental_multimodal_medical_learning_ii_amd.DataRetrieval import CHEXPERT_COMPETITION_CLASSES, create_prompts
+    Fh.K = cxr_optim.K = TR.K = cpu_kernels   # test-only emulation of the kernel wrappers
+    names = list(CHEXPERT_COMPETITION_CLASSES)
+    torch.manual_seed(27)
+    return TR.Trainer(False, create_prompts(names), names, "standard", LR, torch.device("cpu"), None, bert_encoder=_FrozenBert())
+
+
+def _data():
+    from incremental_multimodal_medical_learning_ii_amd import synthetic as syn
+    embs, labels, _ = syn.synthetic_adapter_batch(B * STEPS, seed=29)
+    return embs, labels
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import cpu_kernels
+    tr = _make_trainer(cpu_kernels)
+    assert tr.world == world and tr.rank == rank
+    embs, labels = _data()
+    crit = torch.nn.BCEWithLogitsLoss()
+    losses = [float(tr._train_step((embs[i * B:(i + 1) * B], labels[i * B:(i + 1) * B]), tr.class_names, crit)) for i in range(STEPS)]
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), losses=np.array(losses), flat=tr.optimizer.flat_p.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_adapter_step_matches_single_process_oracle(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_kernels
+    from oracle import ref_step
+    tr = _make_trainer(cpu_kernels)          # same seed: the replicas' initial adapters
+    assert tr.world == 1
+    img = {"layer." + k: v.detach().clone().requires_grad_(True) for k, v in tr.image_adapter.layer.state_dict().items()}
+    txt = {"layer." + k: v.detach().clone().requires_grad_(True) for k, v in tr.text_adapter.layer.state_dict().items()}
+    opt = torch.optim.Adam(list(txt.values()) + list(img.values()), lr=LR)
+    bert_out = torch.stack([tr._bert_embed(tr.prompts[c][k]) for c in tr.class_names for k in ("positive", "negative")])
+    embs, labels = _data()
+    ref_losses = [float(ref_step.adapter_step(img, txt, embs[i * B:(i + 1) * B], labels[i * B:(i + 1) * B], bert_out, opt)[0]) for i in range(STEPS)]
+    r = [np.load(tmp_path / f"r{k}.npz") for k in range(world)]
+    np.testing.assert_array_equal(r[0]["flat"], r[1]["flat"])                    # replicas stay identical
+    for k in range(world):
+        np.testing.assert_allclose(r[k]["losses"], ref_losses, rtol=2e-5)        # every rank reports the global-batch loss
+    # the update equals the single-process one: compare every adapter tensor after 3 Adam steps
+    flat = torch.from_numpy(r[0]["flat"])
+    base = tr.optimizer.flat_p.data_ptr()
+    for mod, ref in ((tr.text_adapter, txt), (tr.image_adapter, img)):
+        for name, p in mod.named_parameters():
+            o = (p.data_ptr() - base) // 4
+            got = flat[o:o + p.numel()].view(p.shape)
+            # (3 Adam steps move a weight by ~3e-3; an entry whose gradient is ~0 takes Adam's sign-like step slightly differently
+            #  when the summation order differs: 1e-5 is 0.3 % of the update, a wrong shard weight would show as ~1e-3)
+            assert float((got - ref[name].detach()).abs().max()) < 1e-5, name
+
+
+def test_joint_step_reduce_ranges_tile_the_flat_gradient_buffer():
+    """`JointContrastiveTrainer.reduce_spans`: the ranges whose all-reduce the backward starts early (text, then the image encoder's
+    stages from the back) are gap-free, disjoint, and together with nothing else cover the whole flat gradient buffer; every
+    parameter's gradient view lies inside the range of its stage."""
+    from incremental_multimodal_medical_learning_ii_amd import image_encoder as IE
+    from incremental_multimodal_medical_learning_ii_amd import optim as cxr_optim
+    from incremental_multimodal_medical_learning_ii_amd.contrastive import JointContrastiveTrainer
+    from incremental_multimodal_medical_learning_ii_amd.health_multimodal.image.model import get_biovil_resnet
+    from incremental_multimodal_medical_learning_ii_amd.health_multimodal.text import CXRBertConfig, CXRBertModel
+    cfg = CXRBertConfig(vocab_size=300, hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=2,
+                        max_position_embeddings=32)
+    im, tm = get_biovil_resnet(None).eval(), CXRBertModel(cfg).eval()
+    tr = JointContrastiveTrainer(im, tm, lr=1e-4)
+    spans = tr.reduce_spans()
+    assert set(spans) == {"text", "head", "layer3", "layer2", "stem"}
+    ordered = sorted(spans.values())
+    assert ordered[0][0] == 0 and ordered[-1][1] == tr.optimizer.numel
+    assert all(a[1] == b[0] for a, b in zip(ordered, ordered[1:]))                # no gap, no overlap
+    assert cxr_optim._complement(list(spans.values()), tr.optimizer.numel) == []
+    base = tr.optimizer.flat_g.data_ptr()
+    for n, p in im.named_parameters():
+        if n.startswith("encoder.encoder.fc."):
+            continue
+        lo, hi = spans[IE.stage_of_param(n)]
+        o = (p.grad.data_ptr() - base) // 4
+        assert lo <= o and o + p.numel() <= hi, n
+    # the stages complete from the back of the network: their ranges sit in the buffer in forward order
+    assert spans["stem"][0] < spans["layer2"][0] < spans["layer3"][0] < spans["head"][0] < spans["text"][0]
+    assert cxr_optim._complement([spans["text"], spans["head"]], tr.optimizer.numel) == [(0, spans["head"][0])]
+    with pytest.raises(ValueError):
+        cxr_optim._complement([(0, 10), (5, 20)], 100)

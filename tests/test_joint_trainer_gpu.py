@@ -1,0 +1,161 @@
+"""The north-star step behind the reference's Trainer surface: `Trainer(..., joint_encoders=...)` runs
+`contrastive.JointContrastiveTrainer.step` inside `train` / `train_class_more_labels_incremental` / `train_class_incremental`, and the
+drivers' data-incremental (`DATA_INCREMENTAL.py:75-90`) and class-incremental (`CLASS_INCREMENTAL.py:67-90`) schedules loop over it.
+Small size: every step's loss against `oracle.ref_step.joint_step` (CPU, same batches in the same order) and the zero-shot
+validation scores of the trained encoders against the oracle's; BASELINE config 3 (5-part data-incremental schedule at batch 1024,
+full models) through `drivers.data_incremental(--joint)`."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu]
+
+from incremental_multimodal_medical_learning_ii_amd import Trainer as TR  # noqa: E402
+from incremental_multimodal_medical_learning_ii_amd import _lib, drivers, synthetic as syn  # noqa: E402
+from incremental_multimodal_medical_learning_ii_amd.DataRetrieval import CHEXPERT_COMPETITION_CLASSES, create_prompts  # noqa: E402
+from incremental_multimodal_medical_learning_ii_amd.health_multimodal import text as T  # noqa: E402
+from incremental_multimodal_medical_learning_ii_amd.health_multimodal.image.model import get_biovil_resnet  # noqa: E402
+
+DEV, TAU, LR = "cuda", 0.07, 1e-4
+CFG = dict(vocab_size=2048, hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=2, max_position_embeddings=32)
+
+
+@pytest.fixture(params=["fp32", "split_bf16"])
+def precision(request):
+    old = _lib.get_precision()
+    _lib.set_precision(request.param)
+    yield request.param
+    _lib.set_precision(old)
+
+
+def _models():
+    im = get_biovil_resnet(None).eval()
+    tm = T.CXRBertModel(T.CXRBertConfig(**CFG)).eval()
+    syn.fill_module_(im)
+    syn.fill_module_(tm)
+    return im, tm
+
+
+def _trainer(tmp_path, tag):
+    im, tm = _models()
+    ip = {k: v.detach().clone() for k, v in im.state_dict().items()}
+    tp = {k: v.detach().clone() for k, v in tm.state_dict().items()}
+    engine = T.TextInferenceEngine(T.SyntheticTokenizer(CFG["vocab_size"]), tm.to(DEV))
+    names = list(CHEXPERT_COMPETITION_CLASSES)
+    writer = TR.ScalarWriter(str(tmp_path / tag))
+    tr = TR.Trainer(False, create_prompts(names), names, "standard", LR, torch.device(DEV), writer, bert_encoder=engine,
+                    joint_encoders={"image_model": im.to(DEV), "temperature": TAU})
+    return tr, ip, tp, engine
+
+
+def _oracle_leaves(ip, tp):
+    leaves = []
+    for d in (ip, tp):
+        for k, v in d.items():
+            if v.dtype == torch.float32 and "running" not in k and not k.startswith("cls.predictions") and ".fc." not in k:
+                v.requires_grad_(True)
+                leaves.append(v)
+    return leaves
+
+
+def _oracle_val_scores(ip, tp, engine, tr, images):
+    """zero-shot scores of `Trainer.val` (Trainer.py:797-837) from the oracle's encoders: (pos + 1) / 2 per class"""
+    from oracle import ref_image, ref_loss, ref_text
+    with torch.no_grad():
+        emb = ref_image.image_model_forward({k: v.detach() for k, v in ip.items()}, images)
+        cols = []
+        for c in tr.class_names:
+            enc = engine.tokenize_input_prompts(tr.prompts[c]["positive"], verbose=False)
+            pe = ref_text.cxrbert_projected({k: v.detach() for k, v in tp.items()}, enc.input_ids.cpu(), enc.attention_mask.cpu(),
+                                            CFG["num_hidden_layers"], CFG["num_attention_heads"], normalize=False)
+            cols.append(ref_loss.pairwise_cosine_similarity(emb, pe.mean(0, keepdim=True)))
+        return (torch.cat(cols, dim=1) + 1) / 2
+
+
+def test_incremental_schedules_over_the_joint_step_match_the_oracle(tmp_path, precision):
+    from oracle import ref_step
+    B, PARTS = 4, 5
+    train, val, _ = TR.Trainer.synthetic_joint_loaders(B * PARTS, 8, 8, B, image_size=64, seq_len=16, vocab=CFG["vocab_size"], eval_batch_size=8)
+    crit = torch.nn.BCEWithLogitsLoss()
+    # ---- data-incremental: 5 contiguous parts, one epoch each (DATA_INCREMENTAL.py:75-90)
+    tr, ip, tp, engine = _trainer(tmp_path, "data")
+    opt = torch.optim.Adam(_oracle_leaves(ip, tp), lr=LR)
+    parts = [list(ld) for ld in TR.Trainer.split_dataloader_data_incremental(train, PARTS)]   # materialised: same batches for both sides
+    assert [len(p) for p in parts] == [1] * PARTS and parts[0][0][0].shape == (B, 3, 64, 64)
+    ref_losses = []
+    for part, batches in enumerate(parts, start=1):
+        tr.train(batches, crit, 1, None, None, part=part, epochs=1, actual_task=part)
+        for images, ids, mask, _ in batches:
+            ref_losses.append(float(ref_step.joint_step(ip, tp, images, ids, mask, TAU, opt, n_layers=CFG["num_hidden_layers"],
+                                                        n_heads=CFG["num_attention_heads"])))
+    got = [v for _, v, _ in tr.writer.scalars("train/Loss")]
+    assert [s for _, _, s in tr.writer.scalars("train/Loss")] == [1, 2, 3, 4, 5]          # the reference's iteration numbering
+    assert len(got) == PARTS and np.allclose(got, ref_losses, rtol=1e-3), (got, ref_losses)
+    # validation of the trained encoders = the zero-shot chain, against the oracle's encoders after the same five steps
+    vb = list(val)
+    y_true, y_pred, y_score = tr._eval_loop(vb, crit, 1, "val")
+    ref_score = _oracle_val_scores(ip, tp, engine, tr, vb[0][0])
+    assert y_score.shape == (8, 5) and np.abs(y_score - ref_score.numpy()).max() < 1e-3
+    assert np.array_equal(y_true, vb[0][3].numpy())
+    m = tr.val(vb, crit, 1, 1, mode="data-inc", tasks_order=1)
+    assert "Accuracy" in m
+    tr.save()
+    assert os.path.exists(os.path.join(tr.writer.log_dir, "image_model.pt")) and os.path.exists(os.path.join(tr.writer.log_dir, "text_model.pt"))
+    # ---- class-incremental: 5 tasks over the contiguous fifths ("class-pos-neg"), MORE_LABELS form, then the single-label form
+    tr, ip, tp, engine = _trainer(tmp_path, "class")
+    opt = torch.optim.Adam(_oracle_leaves(ip, tp), lr=LR)
+    tasks = [list(ld) for ld in TR.Trainer.split_dataloader_data_incremental(TR.Trainer.concat_to_tensor_dataloader(train), 5)]
+    last, ref_losses = 0, []
+    for task, batches in enumerate(tasks):
+        fn = tr.train_class_more_labels_incremental if task % 2 == 0 else tr.train_class_incremental
+        last = fn(batches, crit, 1, None, None, task, last, task + 1)
+        for images, ids, mask, _ in batches:
+            ref_losses.append(float(ref_step.joint_step(ip, tp, images, ids, mask, TAU, opt, n_layers=CFG["num_hidden_layers"],
+                                                        n_heads=CFG["num_attention_heads"])))
+    got = [v for _, v, _ in tr.writer.scalars("train/Loss")]
+    assert last == 5 and np.allclose(got, ref_losses, rtol=1e-3), (got, ref_losses)
+    # continual-learning reset on the encoders: with threshold 1 every entry below the largest change of its tensor is restored
+    tr.model_copy()
+    before = tr.optimizer.flat_p.clone()
+    tr._train_step(tasks[0][0], tr.class_names, crit)
+    tr.myIncremental(1.0, 1)
+    n_reset, n_upd = tr._reset_stats()
+    changed = int((tr.optimizer.flat_p != before).sum())
+    total = sum(p.numel() for p in tr.optimizer.params)
+    assert n_reset + n_upd == total and n_reset > 0.99 * total and 0 < changed <= n_upd
+
+
+def test_label_split_and_joint_batches_are_refused_or_accepted_consistently(tmp_path):
+    train, _, _ = TR.Trainer.synthetic_joint_loaders(40, 8, 8, 4, image_size=32, seq_len=8, vocab=CFG["vocab_size"], eval_batch_size=8)
+    by_label = TR.Trainer.split_dataloader_by_label(train, batch_size=4)            # "class-pos": label-i-positive subsets
+    labels = train.dataset.tensors[-1]
+    assert [len(ld.dataset) for ld in by_label] == [int(labels[:, i].sum()) for i in range(5)]
+    b = next(iter(by_label[0]))
+    assert len(b) == 4 and bool((b[3][:, 0] == 1).all())
+    tr, _, _, _ = _trainer(tmp_path, "refuse")
+    with pytest.raises(ValueError, match="images, input_ids, attention_mask"):
+        tr._train_step((torch.zeros(4, 128), torch.zeros(4, 5)), tr.class_names, torch.nn.BCEWithLogitsLoss())
+
+
+def test_cfg3_data_incremental_joint_at_batch_1024(tmp_path):
+    """BASELINE.json configs[2] on the north-star step: 5-part data-incremental schedule, batch 1024, ResNet-50 (224 px) + 12-layer
+    CXR-BERT (32 tokens), through `drivers.data_incremental --joint`: every part trains, validates and tests; losses finite and in
+    the range of an InfoNCE loss over 1024 pairs."""
+    old = _lib.get_precision()
+    _lib.set_precision("split_bf16")
+    try:
+        args = drivers.make_parser().parse_args(["data-inc", "--joint", "--batch-size", "1024", "--n-train", "5120", "--n-eval", "256",
+                                                 "--epochs", "1", "--parts", "5", "--lr", "1e-6", "--log-root", str(tmp_path)])
+        tr, m = drivers.data_incremental(args)
+    finally:
+        _lib.set_precision(old)
+    assert m is not None and "Accuracy" in m
+    with open(os.path.join(tr.writer.log_dir, "scalars.jsonl")) as f:
+        rows = [json.loads(line) for line in f]
+    losses = [r["value"] for r in rows if r["tag"] == "train/Loss"]
+    assert len(losses) == 5 and all(math.isfinite(v) and 0.5 * math.log(1024) < v < 3 * math.log(1024) for v in losses), losses
+    assert tr.optimizer.steps == 5 and tr.optimizer.numel > 130_000_000

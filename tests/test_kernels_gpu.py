@@ -452,9 +452,10 @@ def test_embed_ln_and_scatter():
     assert torch.equal(out1, out2), "the scatter must be deterministic (no atomics)"
 
 
-@pytest.mark.parametrize("L,ragged", [(32, False), (32, True), (17, True), (64, False), (16, "empty")])
+@pytest.mark.parametrize("L,ragged", [(32, False), (32, True), (17, True), (64, False), (16, "empty"),
+                                      (65, True), (100, False), (200, True), (512, True), (96, "empty")])   # > 64: the tiled kernels
 def test_attention_fwd_bwd(L, ragged):
-    B, nH, dH = 3, 4, 64
+    B, nH, dH = 3, 4, (64 if L != 100 else 32)
     qkv = rnd(B * L, 3 * nH * dH, scale=0.7).requires_grad_(True)
     mask = torch.ones(B, L, dtype=torch.int64)
     if ragged:

@@ -122,11 +122,11 @@ def test_cfg2_joint_step_batch_256_full_models():
     the CPU oracle would take minutes.  The split-bf16 product path against the exact-fp32 path of the same kernels, for a FIXED
     cotangent on the embeddings:
       * embeddings, loss, every probed BERT gradient and the image projector's output layer: within the north star's 1e-3;
-      * gradients BEHIND ReLUs of the image encoder (projector.0, layer3, layer1): the two precisions' forward passes differ in
-        the last bits, so of the 2.8e9 ReLU decisions of this batch a few 1e-5 fall on the other side of zero, and the gradient —
-        discontinuous there — moves by sqrt(that fraction) ~ 3e-3 (measured r2l: 7e-4 / 2.8e-3 / 5.6e-3, growing with depth).
-        The oracle tests compare under imposed decisions; here the bound is 2e-2 and the backward kernels are
-        checked instead through what must hold exactly: linearity in the cotangent under one set of decisions (1e-4);
+      * gradients BEHIND ReLUs of the image encoder (projector.0, layer3, layer1) are NOT compared free-running: the two
+        precisions' forward passes differ in the last bits, a few 1e-5 of the 2.8e9 ReLU decisions of this batch fall on the other
+        side of zero and the gradient is discontinuous there.  They are compared at this size under the fp32 forward's decisions,
+        every tensor within 1e-3, in tests/test_precision_gpu.py; here the backward kernels are additionally checked through what
+        must hold exactly: linearity in the cotangent under one set of decisions (1e-4);
       * run-to-run bit equality, and a loss that falls.
     (The InfoNCE gradient itself is not compared across precisions: with synthetic weights the embeddings of a batch are nearly
     parallel, (softmax - onehot) @ T cancels to ~1e-3 of its terms, and a 1e-5 change of the embeddings moves it by 2e-3.)"""
@@ -166,7 +166,7 @@ def test_cfg2_joint_step_batch_256_full_models():
             errs["grad " + name] = float((gb - ga).norm() / ga.norm())
         print("cfg2 split_bf16 vs fp32:", errs)
         behind_relu = ("grad encoder.encoder.layer3.2.conv2.weight", "grad encoder.encoder.layer1.0.conv1.weight", "grad projector.model.0.weight")
-        assert math.isfinite(b[0]) and all(v < (2e-2 if k in behind_relu else 1e-3) for k, v in errs.items()), errs
+        assert math.isfinite(b[0]) and all(v < 1e-3 for k, v in errs.items() if k not in behind_relu), errs
         # linearity of the image backward in the cotangent (same forward, same decisions): g(c1) + g(c2) == g(c1 + c2)
         _lib.set_precision("split_bf16")
         gsum = None
