@@ -102,12 +102,29 @@ __device__ __forceinline__ uint4 f4_bits(float a, float b, float c, float d) {
   return make_uint4(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
 }
 
+// Experiment switch (round 3, measured and NOT kept): 1 = pipeline the side inputs of the LDS-DMA kernels' epilogues (see epi_rows).
+// With it the data-gradient launches of the step took 20.34 instead of 20.45 ms and the step 154.0 instead of 155.3 ms — inside
+// the box-to-box spread — while the 256x256 instantiations went from 249 registers to 256 + 60 spilled (scratch): the epilogue is
+// bound by its stores (256 KB per tile), not by the latency of its side inputs.
+#ifndef CXRK_EPI_PIPE
+#define CXRK_EPI_PIPE 0
+#endif
+constexpr bool epi_has_side(unsigned f) { return (f & (EF_RES_F32 | EF_RES_PL | EF_AUX_SIGN | EF_AUX_GELU | EF_AUX_MASK)) != 0u; }
+constexpr bool epi_two_fp32_sides(unsigned f) { return (f & EF_RES_F32) != 0u && (f & (EF_AUX_SIGN | EF_AUX_GELU)) != 0u; }
+
 #define EH(bit, rt) (GEN ? (rt) : ((F & (bit)) != 0u))
 
-template <unsigned F>
-__device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0, int col0,
-                                      int part, int z, int lane) {
+// NSUB 64-row slabs of a wave's outputs (acc[s] = rows 64 s .. 64 s + 63 of the block at row0; NSUB = 2: the 128 x 64 outputs of a
+// wave of the 256 x 256 tile) go through 2 NSUB halves of 32 rows.
+// PIPE (compiled-in feature sets on the LDS-DMA kernels): the side inputs (residual, mask bits, GELU' source) of an 8-row pass of
+// half h + 1 are requested as soon as the same pass of half h has been stored, so only the first half's loads are waited for at
+// full memory latency; the un-pipelined form (generic feature set, register-staged kernels) loads the side inputs of a half and
+// consumes them at once — a round trip per half with nothing of this wave in between.
+template <unsigned F, int NSUB, bool PIPE>
+__device__ __forceinline__ void epi_rows(f32x16 (*acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0, int col0,
+                                         int part, int z, int lane) {
   constexpr bool GEN = (F & EF_GENERIC) != 0u;
+  static_assert(!(GEN && PIPE), "the generic feature set is not pipelined");
   const bool outpl = EH(EF_OUTPL, ep.Cp != nullptr), has_bias = EH(EF_BIAS, ep.bias != nullptr);
   const bool res_f32 = EH(EF_RES_F32, ep.R != nullptr), res_pl = EH(EF_RES_PL, ep.Rp != nullptr);
   const bool relu = EH(EF_RELU, ep.act == 1), gelu = EH(EF_GELU, ep.act == 2);
@@ -142,9 +159,9 @@ __device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, 
   }
   float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  // Wave-uniform descriptors at the sub-tile origin (row0, col0); lane offsets below are relative to it.  In the remapped form
-  // (GEMM row (n,a,b) -> pixel (n, 2a+ph, 2b+pw)) the origin is the pixel of the sub-tile's first row and a lane adds the
-  // distance of its own pixel from it (the map is monotonic, and 64 consecutive GEMM rows stay within a few image rows).
+  // Wave-uniform descriptors at the block origin (row0, col0); lane offsets below are relative to it.  In the remapped form
+  // (GEMM row (n,a,b) -> pixel (n, 2a+ph, 2b+pw)) the origin is the pixel of the block's first row and a lane adds the
+  // distance of its own pixel from it (the map is monotonic, and 128 consecutive GEMM rows stay within a few image rows).
   const long rbase = remap ? epi_row(ep, row0 < M ? row0 : M - 1) : (long)row0;   // remap is monotonic: lane offsets stay >= 0
   float* Cf = ep.C ? ep.C + (long)z * ep.slab_stride : nullptr;
   const __amdgpu_buffer_rsrc_t d_out = tile_rsrc(outpl ? (const void*)(ep.Cp + rbase * ep.ldc + col0) : (const void*)(Cf + rbase * ep.ldc + col0));
@@ -156,71 +173,63 @@ __device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, 
   const __amdgpu_buffer_rsrc_t d_min = tile_rsrc(ep.maskin + rbase * ep.ldmaskin + (col0 >> 3), aux_mask);
   const __amdgpu_buffer_rsrc_t d_mout = tile_rsrc(ep.maskout + rbase * ep.ldmaskout + (col0 >> 3), maskout);
 
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) st[((e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[i][j][e];
-    __builtin_amdgcn_wave_barrier();  // LDS serves one wave's accesses in issue order; keep the compiler from reordering
+  // side inputs of PF 8-row passes (all four of a half in the compiled-in feature sets; the generic form, which may carry every
+  // side input at once, goes pass by pass to stay inside the register budget; an fp32 residual AND an fp32 aux tensor — the
+  // fp32-mode data gradient with identity branch — are four 16-byte loads per pass: two passes ahead is what the 168-register
+  // budget of the three-blocks-per-CU kernels holds without spilling)
+  constexpr int PF = GEN ? 1 : (((F & EF_RES_F32) != 0u && (F & (EF_AUX_SIGN | EF_AUX_GELU)) != 0u) ? 2 : 4);
+  static_assert(!PIPE || PF == 4, "the pipelined form keeps the side inputs of a whole half");
+  struct Side { unsigned dead[PF]; unsigned rowo[PF]; uint4 r0v[PF], r1v[PF], a0v[PF], a1v[PF]; unsigned mk[PF]; };
 
-    // ---- side inputs of PF 8-row passes at a time (all four of this half in the compiled-in feature sets; the generic form, which
-    //      may carry every side input at once, goes pass by pass to stay inside the register budget)
-    // (an fp32 residual AND an fp32 aux tensor — the fp32-mode data gradient with identity branch — are four 16-byte loads per pass:
-    //  two passes ahead is what the 168-register budget of the three-blocks-per-CU kernels holds without spilling)
-    constexpr int PF = GEN ? 1 : (((F & EF_RES_F32) != 0u && (F & (EF_AUX_SIGN | EF_AUX_GELU)) != 0u) ? 2 : 4);
-#pragma unroll
-    for (int ug = 0; ug < 4; ug += PF) {
-    unsigned dead[PF]; long rows[PF];
-    uint4 r0v[PF], r1v[PF], a0v[PF], a1v[PF]; unsigned mk[PF];
-#pragma unroll
-    for (int up = 0; up < PF; ++up) {
-      const int u = up, ua = ug + up;
-      const int rl = i * 32 + ua * 8 + rq;              // row inside the sub-tile
+  // request the side inputs of pass ua (8 rows) of half hh (rows 32 hh .. 32 hh + 31 of the block) into slot u
+  auto load_side = [&](Side& sd, int u, int hh, int ua) {
+    {
+      const int rl = hh * 32 + ua * 8 + rq;              // row inside the block
       const int grow = row0 + rl;
-      dead[u] = grow < M ? 0u : VOFF_OOB;   // row only; the column part (deadA / deadB) is OR-ed in per access
-      rows[u] = remap ? epi_row(ep, grow < M ? grow : M - 1) - rbase : (long)rl;
-      const unsigned rowo = (unsigned)rows[u];
+      sd.dead[u] = grow < M ? 0u : VOFF_OOB;   // row only; the column part (deadA) is OR-ed in per access
+      sd.rowo[u] = (unsigned)(remap ? epi_row(ep, grow < M ? grow : M - 1) - rbase : (long)rl);
+      const unsigned rowo = sd.rowo[u];
       if (res_pl) {
         if constexpr (MAPF) {   // 4 + 4 columns: two 8-byte pieces of each plane
-          const unsigned oa = ((rowo * (unsigned)ep.ldr + cA) * 2u) | dead[u] | deadA;
+          const unsigned oa = ((rowo * (unsigned)ep.ldr + cA) * 2u) | sd.dead[u] | deadA;
           const uint2 ha = buf_load8(d_res, oa), hb = buf_load8(d_res, oa + DB2), la = buf_load8(d_res2, oa), lb = buf_load8(d_res2, oa + DB2);
-          r0v[u] = make_uint4(ha.x, ha.y, hb.x, hb.y); r1v[u] = make_uint4(la.x, la.y, lb.x, lb.y);
+          sd.r0v[u] = make_uint4(ha.x, ha.y, hb.x, hb.y); sd.r1v[u] = make_uint4(la.x, la.y, lb.x, lb.y);
         } else {
-          const unsigned o = ((rowo * (unsigned)ep.ldr + cA) * 2u) | dead[u] | deadA;
-          r0v[u] = buf_load16(d_res, o); r1v[u] = buf_load16(d_res2, o);
+          const unsigned o = ((rowo * (unsigned)ep.ldr + cA) * 2u) | sd.dead[u] | deadA;
+          sd.r0v[u] = buf_load16(d_res, o); sd.r1v[u] = buf_load16(d_res2, o);
         }
       } else if (res_f32) {
-        const unsigned o = ((rowo * (unsigned)ep.ldr + cA) * 4u) | dead[u] | deadA;
-        r0v[u] = buf_load16(d_res, o); r1v[u] = buf_load16(d_res, o + DB4);
+        const unsigned o = ((rowo * (unsigned)ep.ldr + cA) * 4u) | sd.dead[u] | deadA;
+        sd.r0v[u] = buf_load16(d_res, o); sd.r1v[u] = buf_load16(d_res, o + DB4);
       }
       if (aux_sign || aux_gelu) {
-        const unsigned o = ((rowo * (unsigned)ep.ldaux + cA) * 4u) | dead[u] | deadA;
-        a0v[u] = buf_load16(d_aux, o); a1v[u] = buf_load16(d_aux, o + DB4);
+        const unsigned o = ((rowo * (unsigned)ep.ldaux + cA) * 4u) | sd.dead[u] | deadA;
+        sd.a0v[u] = buf_load16(d_aux, o); sd.a1v[u] = buf_load16(d_aux, o + DB4);
       }
-      if (aux_mask) mk[u] = __builtin_amdgcn_raw_buffer_load_b8(d_min, (int)((rowo * (unsigned)ep.ldmaskin + c8) | dead[u] | deadA), 0, 0);
+      if (aux_mask) sd.mk[u] = __builtin_amdgcn_raw_buffer_load_b8(d_min, (int)((rowo * (unsigned)ep.ldmaskin + c8) | sd.dead[u] | deadA), 0, 0);
     }
-    // ---- values, stores
-#pragma unroll
-    for (int up = 0; up < PF; ++up) {
-      const int u = up, ua = ug + up;
+  };
+
+  // values and stores of pass ua of half hh, from the staged accumulators and the side inputs in slot u of `sd`
+  auto finish_pass = [&](const Side& sd, int u, int hh, int ua) {
+    {
       const float* sp = st + (ua * 8 + rq) * 64;
       const float4 s0 = *reinterpret_cast<const float4*>(sp + cA), s1 = *reinterpret_cast<const float4*>(sp + cB);
       float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-      const unsigned rowo = (unsigned)rows[u];
+      const unsigned rowo = sd.rowo[u];
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = ep.alpha * v[q] + bv[q];
       if (res_pl) {
-        float rv[8]; planes_unpack8(r0v[u], r1v[u], rv);
+        float rv[8]; planes_unpack8(sd.r0v[u], sd.r1v[u], rv);
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] += rv[q];
       } else if (res_f32) {
-        const unsigned rw[8] = {r0v[u].x, r0v[u].y, r0v[u].z, r0v[u].w, r1v[u].x, r1v[u].y, r1v[u].z, r1v[u].w};
+        const unsigned rw[8] = {sd.r0v[u].x, sd.r0v[u].y, sd.r0v[u].z, sd.r0v[u].w, sd.r1v[u].x, sd.r1v[u].y, sd.r1v[u].z, sd.r1v[u].w};
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] += __builtin_bit_cast(float, rw[q]);
       }
       if (has_c2) {
-        const unsigned o = ((rowo * (unsigned)ep.ldc2 + cA) * 4u) | dead[u] | deadA;
+        const unsigned o = ((rowo * (unsigned)ep.ldc2 + cA) * 4u) | sd.dead[u] | deadA;
         buf_store16(d_c2, o, f4_bits(v[0], v[1], v[2], v[3]), false);
         buf_store16(d_c2, o + DB4, f4_bits(v[4], v[5], v[6], v[7]), false);
       }
@@ -234,9 +243,9 @@ __device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, 
       }
       if (aux_mask) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = ((mk[u] >> q) & 1u) ? v[q] : 0.f;
+        for (int q = 0; q < 8; ++q) v[q] = ((sd.mk[u] >> q) & 1u) ? v[q] : 0.f;
       } else if (aux_sign || aux_gelu) {
-        const unsigned aw[8] = {a0v[u].x, a0v[u].y, a0v[u].z, a0v[u].w, a1v[u].x, a1v[u].y, a1v[u].z, a1v[u].w};
+        const unsigned aw[8] = {sd.a0v[u].x, sd.a0v[u].y, sd.a0v[u].z, sd.a0v[u].w, sd.a1v[u].x, sd.a1v[u].y, sd.a1v[u].z, sd.a1v[u].w};
         if (aux_sign) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] = __builtin_bit_cast(float, aw[q]) > 0.f ? v[q] : 0.f;
@@ -246,16 +255,16 @@ __device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, 
         }
       }
       if (colsum) {   // rows outside the tensor contribute nothing (dead columns are dropped at the final store)
-        const bool livel = dead[u] == 0u;
+        const bool livel = sd.dead[u] == 0u;
 #pragma unroll
         for (int q = 0; q < 8; ++q) bs[q] += livel ? v[q] : 0.f;
       }
       if (outpl) {
-        const unsigned oo = ((rowo * (unsigned)ep.ldc + cA) * 2u) | dead[u] | deadA;
+        const unsigned oo = ((rowo * (unsigned)ep.ldc + cA) * 2u) | sd.dead[u] | deadA;
         uint4 hv, lv; planes_pack8(v, hv, lv);
         buf_store16(d_out, oo, hv, nt); buf_store16(d_out2, oo, lv, nt);
       } else {
-        const unsigned oo = ((rowo * (unsigned)ep.ldc + cA) * 4u) | dead[u] | deadA;
+        const unsigned oo = ((rowo * (unsigned)ep.ldc + cA) * 4u) | sd.dead[u] | deadA;
         buf_store16(d_out, oo, f4_bits(v[0], v[1], v[2], v[3]), nt);
         buf_store16(d_out, oo + DB4, f4_bits(v[4], v[5], v[6], v[7]), nt);
       }
@@ -265,29 +274,80 @@ __device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, 
         for (int o = 1; o < 8; o <<= 1) { w0 |= (unsigned)__shfl_xor((int)w0, o, 64); w1 |= (unsigned)__shfl_xor((int)w1, o, 64); }
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         const u32x2 w = {w0, w1};
-        const int grow = row0 + i * 32 + ua * 8 + rq;
-        const unsigned mo = (rowo * (unsigned)ep.ldmaskout) | ((c8 == 0 && grow < M && col0 < N) ? 0u : VOFF_OOB);
+        const unsigned mo = (rowo * (unsigned)ep.ldmaskout) | ((c8 == 0 && sd.dead[u] == 0u && col0 < N) ? 0u : VOFF_OOB);
         __builtin_amdgcn_raw_buffer_store_b64(w, d_mout, (int)mo, 0, 0);
       }
     }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (colsum) {  // add the eight row lanes of the wave (lanes c8 + 8*rq), lanes 0..7 write
+  };
+
+  auto flush_colsum = [&](int prt) {  // add the eight row lanes of the wave (lanes c8 + 8*rq), lanes 0..7 write; restart the sums
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       float t = bs[q];
       t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
       bs[q] = t;
     }
-    const __amdgpu_buffer_rsrc_t d_cs = tile_rsrc(ep.colsum_part + (long)part * N + col0);
+    const __amdgpu_buffer_rsrc_t d_cs = tile_rsrc(ep.colsum_part + (long)prt * N + col0);
     const unsigned keep = rq == 0 ? 0u : VOFF_OOB;
     const unsigned o = (unsigned)(cA * 4) | keep | deadA;
     buf_store16(d_cs, o, f4_bits(bs[0], bs[1], bs[2], bs[3]), false);
     buf_store16(d_cs, o + DB4, f4_bits(bs[4], bs[5], bs[6], bs[7]), false);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bs[q] = 0.f;
+  };
+
+  // accumulators of half hh -> the wave's private LDS staging area, rows of the half x 64 columns
+  auto stage = [&](int hh) {
+    const int s_ = hh >> 1, i = hh & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[((e & 3) + 8 * (e >> 2) + 4 * h) * 64 + j * 32 + r] = acc[s_][i][j][e];
+    __builtin_amdgcn_wave_barrier();  // LDS serves one wave's accesses in issue order; keep the compiler from reordering
+  };
+
+  constexpr int NHALF = 2 * NSUB;
+  Side sd;
+  if constexpr (PIPE) {
+    // slot u holds the side inputs of pass u of the current half; the moment pass u has been combined and stored, the slot is
+    // re-requested for pass u of the NEXT half: that load is in flight for a whole half's worth of staging, arithmetic and stores
+    // (one set of side-input registers, as in the un-pipelined form)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_side(sd, u, 0, u);
+#pragma unroll
+    for (int hh = 0; hh < NHALF; ++hh) {
+      stage(hh);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        finish_pass(sd, u, hh, u);
+        if (hh + 1 < NHALF) load_side(sd, u, hh + 1, u);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (colsum && (hh & 1)) flush_colsum(part + (hh >> 1));
+    }
+  } else {
+#pragma unroll
+    for (int hh = 0; hh < NHALF; ++hh) {
+      stage(hh);
+#pragma unroll
+      for (int ug = 0; ug < 4; ug += PF) {
+#pragma unroll
+        for (int up = 0; up < PF; ++up) load_side(sd, up, hh, ug + up);
+#pragma unroll
+        for (int up = 0; up < PF; ++up) finish_pass(sd, up, hh, ug + up);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (colsum && (hh & 1)) flush_colsum(part + (hh >> 1));
+    }
   }
 }
 #undef EH
+
+template <unsigned F>
+__device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0, int col0,
+                                      int part, int z, int lane) {
+  epi_rows<F, 1, false>(&acc, ep, st, M, N, row0, col0, part, z, lane);
+}
 
 template <int KIND>
 __device__ __forceinline__ void epi64_dispatch(int kind, f32x16 (&acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0,
@@ -296,6 +356,17 @@ __device__ __forceinline__ void epi64_dispatch(int kind, f32x16 (&acc)[2][2], co
   else {
     if (kind == KIND) epi64<EPI_KINDS[KIND]>(acc, ep, st, M, N, row0, col0, part, z, lane);
     else epi64_dispatch<KIND + 1>(kind, acc, ep, st, M, N, row0, col0, part, z, lane);
+  }
+}
+
+// The LDS-DMA kernels (gemm_pw.h): NSUB slabs of 64 rows per wave, compiled-in feature sets pipelined (see epi_rows).
+template <int KIND, int NSUB>
+__device__ __forceinline__ void epi_pw_dispatch(int kind, f32x16 (*acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0,
+                                                int col0, int part, int z, int lane) {
+  if constexpr (KIND >= EPI_NKINDS) epi_rows<EF_GENERIC, NSUB, false>(acc, ep, st, M, N, row0, col0, part, z, lane);
+  else {
+    if (kind == KIND) epi_rows<EPI_KINDS[KIND], NSUB, (CXRK_EPI_PIPE != 0) && epi_has_side(EPI_KINDS[KIND]) && !epi_two_fp32_sides(EPI_KINDS[KIND])>(acc, ep, st, M, N, row0, col0, part, z, lane);
+    else epi_pw_dispatch<KIND + 1, NSUB>(kind, acc, ep, st, M, N, row0, col0, part, z, lane);
   }
 }
 

@@ -530,7 +530,9 @@ __global__ __launch_bounds__(CFG::NT, CFG::WAVES_PER_SIMD) void gemm_pw_kernel(t
   la.init(pa, m0, wave, lane);
   lb.init(pb, n0, wave, lane);
 
-  f32x16 acc0[2][2], acc1[2][2];   // rows 0-63 / 64-127 of the wave's outputs (acc1 is dead when WTM == 2)
+  f32x16 acc[2][2][2];             // [slab][i][j]: rows 0-63 / 64-127 of the wave's outputs (slab 1 is dead when WTM == 2)
+  f32x16 (&acc0)[2][2] = acc[0];
+  f32x16 (&acc1)[2][2] = acc[1];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -612,9 +614,9 @@ __global__ __launch_bounds__(CFG::NT, CFG::WAVES_PER_SIMD) void gemm_pw_kernel(t
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();   // every wave is done with the operand buffers: they become the epilogue's transpose staging
   float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 64);
-  // planes operands are always 16-byte aligned (launch_gemm_pw refuses anything else): the fast epilogue only
-  epi64_dispatch<0>(ep.kind, acc0, ep, stg, M, N, m0 + arow, n0 + bcol, mt * (CFG::TM / 64) + wm * (WTM / 2), z, lane);
-  if constexpr (WTM == 4) epi64_dispatch<0>(ep.kind, acc1, ep, stg, M, N, m0 + arow + 64, n0 + bcol, mt * (CFG::TM / 64) + wm * 2 + 1, z, lane);
+  // planes operands are always 16-byte aligned (launch_gemm_pw refuses anything else): the fast epilogue only.  The wave's WTM / 2
+  // slabs of 64 rows go through ONE pipelined pass (side inputs of the next 32-row half requested while this one is stored).
+  epi_pw_dispatch<0, WTM / 2>(ep.kind, acc, ep, stg, M, N, m0 + arow, n0 + bcol, mt * (CFG::TM / 64) + wm * (WTM / 2), z, lane);
   PW_STAMP(3);
   if (ep.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PW_STAMP(4); }
 #undef PW_STAMP

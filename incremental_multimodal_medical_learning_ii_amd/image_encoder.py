@@ -235,6 +235,21 @@ def _unit_params_bwd(i, s, fold, p, bufs, x, dy, sumdy, N, H, W, sink: GradSink,
         K.conv_bwd_params(x, dy, *args, s.cin, s.cpad, s.cout, s.k, s.k, s.stride, s.pad)
 
 
+_side_streams: dict = {}
+
+
+def _wgrad_stream(dev) -> Optional["torch.cuda.Stream"]:
+    """The side stream the parameter-gradient launches of the backward run on (CXRK_WGRAD_STREAM=1; experiment, see `_backward`)."""
+    import os
+    if os.environ.get("CXRK_WGRAD_STREAM", "0") != "1" or dev.type != "cuda":
+        return None
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def _dgrad(i, s, fold, dy, residual, relu, N, H, W, pl, want_sums):
     """Data gradient of unit i, masked by `relu` (planes mode: the bit mask of the tensor the gradient flows into; fp32 mode:
     that tensor itself).  want_sums: also the column sums of the result (-> (dx, sums[C]))."""
@@ -267,6 +282,32 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
     in place: "head" after the projector and layer4, "layer3", "layer2", and "stem" (layer1 + stem) at the end — only while no
     gradient of the stage had to be returned to autograd as a fresh tensor."""
     fold, x0, stem, idx, pooled, binfo, last, pj1, mp, w3p, (N, H, W, Hs, Ws, h, w), pl = state
+    # Experiment (CXRK_WGRAD_STREAM=1): the data-gradient chain is the critical path of this backward; the parameter gradients of a
+    # unit (weight gradient GEMM, its slab reduction, the BatchNorm gamma / beta kernels) depend on it but nothing in the chain
+    # depends on them, so they run on a side stream and fill the tails of the chain's launches.  Tensors they read are marked as in
+    # use by that stream (the caching allocator then does not hand their memory out again before the side stream has passed).
+    main = torch.cuda.current_stream(p[0].device) if p[0].is_cuda else None
+    side = _wgrad_stream(p[0].device) if p[0].is_cuda else None
+
+    def params_bwd(i, s_, x_, dy_, sum_, N_, H_, W_, pl_):
+        if side is None:
+            return _unit_params_bwd(i, s_, fold, p, bufs, x_, dy_, sum_, N_, H_, W_, sink, pl_)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            _unit_params_bwd(i, s_, fold, p, bufs, x_, dy_, sum_, N_, H_, W_, sink, pl_)
+        for t in (x_, dy_, sum_):
+            if t is not None:
+                (t.t if isinstance(t, Planes) else t).record_stream(side)
+
+    def report(stage):
+        if on_grads_ready is None:
+            return
+        if side is None:
+            return on_grads_ready(stage)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):     # the range's all-reduce is ordered behind BOTH streams' gradient writes
+            on_grads_ready(stage)
+
     ns = len(specs)
     ip = ns - 1
     w3 = p[3 * ns]
@@ -303,7 +344,7 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
         g = K.linear_bwd_data(dpj2, w3m, aux=pj1m, auxmode=K.AUX_RELU_MASK)
         sum_p = K.colsum(g, torch.empty(g.shape[1], dtype=torch.float32, device=dev))
         g = g.view(N, h, w, -1)
-    _unit_params_bwd(ip, specs[ip], fold, p, bufs, last, g, sum_p, N, h, w, sink, pl)
+    params_bwd(ip, specs[ip], last, g, sum_p, N, h, w, pl)
 
     nb = len(blocks)
 
@@ -318,15 +359,15 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
         s1, s2, s3 = specs[blk["c1"]], specs[blk["c2"]], specs[blk["c3"]]
         # out = relu(bn3(conv3(o2)) + identity): g (already masked by out > 0) is dy of bn3 and of the downsample BN; its
         # channel sums gs were reduced by the kernel that produced g
-        _unit_params_bwd(blk["c3"], s3, fold, p, bufs, o2, g, gs, N, h2, w2, sink, pl)
+        params_bwd(blk["c3"], s3, o2, g, gs, N, h2, w2, pl)
         d2, q2 = _dgrad(blk["c3"], s3, fold, g, None, m2 if pl else o2, N, h2, w2, pl, True)
-        _unit_params_bwd(blk["c2"], s2, fold, p, bufs, o1, d2, q2, N, hi, wi, sink, pl)
+        params_bwd(blk["c2"], s2, o1, d2, q2, N, hi, wi, pl)
         d1, q1 = _dgrad(blk["c2"], s2, fold, d2, None, m1 if pl else o1, N, hi, wi, pl, True)
         del d2
-        _unit_params_bwd(blk["c1"], s1, fold, p, bufs, cur, d1, q1, N, hi, wi, sink, pl)
+        params_bwd(blk["c1"], s1, cur, d1, q1, N, hi, wi, pl)
         if blk["ds"] is not None:
             sd = specs[blk["ds"]]
-            _unit_params_bwd(blk["ds"], sd, fold, p, bufs, cur, g, gs, N, hi, wi, sink, pl)
+            params_bwd(blk["ds"], sd, cur, g, gs, N, hi, wi, pl)
             res = _dgrad(blk["ds"], sd, fold, g, None, None, N, hi, wi, pl, False)
         else:
             res = g
@@ -340,7 +381,7 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
             # the first block of layer4 / layer3 / layer2 is done: every gradient from its first unit onwards is complete
             stage = {LAYERS[0] + LAYERS[1] + LAYERS[2]: "head", LAYERS[0] + LAYERS[1]: "layer3", LAYERS[0]: "layer2"}[bi]
             if all(r is None for r in sink.ret[3 * blk["c1"]:]):
-                on_grads_ready(stage)
+                report(stage)
     if pl:
         ds = K.maxpool_bwd_pl(g, idx, pooled, Hs, Ws)
     else:
@@ -348,9 +389,11 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
     if _debug is not None:
         _debug["ds"], _debug["x0"] = ds, x0
     sum_s = K.colsum(ds.view(-1, ds.shape[-1]), torch.empty(ds.shape[-1], dtype=torch.float32, device=dev))
-    _unit_params_bwd(0, specs[0], fold, p, bufs, x0, ds, sum_s, N, H, W, sink, False)   # fp32 operands (the image), split on the fly in split_bf16 mode
+    params_bwd(0, specs[0], x0, ds, sum_s, N, H, W, False)   # fp32 operands (the image), split on the fly in split_bf16 mode
     if on_grads_ready is not None and all(r is None for r in sink.ret):
-        on_grads_ready("stem")
+        report("stem")
+    if side is not None:
+        main.wait_stream(side)      # autograd / the optimiser continue on the main stream
     return sink.ret
 
 

@@ -13,4 +13,4 @@ def key(k):
     m = re.search(r"(gemm_\w+_kernel)<cxrk::(\w+)<[^>]*>, cxrk::(\w+)<[^>]*>\s*(?:, (\d), (\d))?\s*>", k)
     if m:
         return f"{m.group(1)}<{m.group(2)},{m.group(3)}" + (f",{m.group(4)},{m.group(5)}>" if m.group(4) else ">")
-    return re.sub(r"\(.*", "", k).replace("(anonymous namespace)::", "").replace("void ", "")[:50]
+    return re.sub(r"\(.*", "", k.replace("(anonymous namespace)::", "")).replace("void ", "").replace("cxrk::", "")[:50]

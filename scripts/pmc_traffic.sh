@@ -6,5 +6,5 @@ set -u
 OUT=$1; R=$GRAFT_REPO_ROOT; mkdir -p $R/$OUT
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $R/$OUT/$c -o pmc --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-secondary --no-cpu-baseline --no-roofline > $R/$OUT/$c.log 2>&1 || echo "pass $c failed"
+  rocprofv3 --pmc $c --kernel-trace -d $R/$OUT/$c -o pmc --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-secondary --no-cpu-baseline --no-roofline --no-bn-calibration --lr 1e-7 > $R/$OUT/$c.log 2>&1 || echo "pass $c failed"
 done

@@ -20,16 +20,9 @@ from incremental_multimodal_medical_learning_ii_amd.DataRetrieval import CHEXPER
 from incremental_multimodal_medical_learning_ii_amd.health_multimodal import text as T  # noqa: E402
 from incremental_multimodal_medical_learning_ii_amd.health_multimodal.image.model import get_biovil_resnet  # noqa: E402
 
-DEV, TAU, LR = "cuda", 0.07, 1e-4
+DEV, TAU, LR = "cuda", 0.07, 1e-5   # Adam moves every weight by ~lr per step whatever its gradient: at 1e-4 two correct trajectories
+#                                      (1e-5 apart in their gradients in split-bf16 mode) drift to 3e-3 in the loss within five steps
 CFG = dict(vocab_size=2048, hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=2, max_position_embeddings=32)
-
-
-@pytest.fixture(params=["fp32", "split_bf16"])
-def precision(request):
-    old = _lib.get_precision()
-    _lib.set_precision(request.param)
-    yield request.param
-    _lib.set_precision(old)
 
 
 def _models():
@@ -76,7 +69,7 @@ def _oracle_val_scores(ip, tp, engine, tr, images):
         return (torch.cat(cols, dim=1) + 1) / 2
 
 
-def test_incremental_schedules_over_the_joint_step_match_the_oracle(tmp_path, precision):
+def test_incremental_schedules_over_the_joint_step_match_the_oracle(tmp_path, precision, monkeypatch):
     from oracle import ref_step
     B, PARTS = 4, 5
     train, val, _ = TR.Trainer.synthetic_joint_loaders(B * PARTS, 8, 8, B, image_size=64, seq_len=16, vocab=CFG["vocab_size"], eval_batch_size=8)
@@ -106,8 +99,11 @@ def test_incremental_schedules_over_the_joint_step_match_the_oracle(tmp_path, pr
     tr.save()
     assert os.path.exists(os.path.join(tr.writer.log_dir, "image_model.pt")) and os.path.exists(os.path.join(tr.writer.log_dir, "text_model.pt"))
     # ---- class-incremental: 5 tasks over the contiguous fifths ("class-pos-neg"), MORE_LABELS form, then the single-label form
+    # (with `Trainer.OPTIM = "sgd"`, the reference's other optimiser, Trainer.py:176-178: updates proportional to the gradient, so
+    #  the two trajectories stay together and the comparison is tight)
+    monkeypatch.setattr(TR, "OPTIM", "sgd")
     tr, ip, tp, engine = _trainer(tmp_path, "class")
-    opt = torch.optim.Adam(_oracle_leaves(ip, tp), lr=LR)
+    opt = torch.optim.SGD(_oracle_leaves(ip, tp), lr=LR)
     tasks = [list(ld) for ld in TR.Trainer.split_dataloader_data_incremental(TR.Trainer.concat_to_tensor_dataloader(train), 5)]
     last, ref_losses = 0, []
     for task, batches in enumerate(tasks):
@@ -117,7 +113,10 @@ def test_incremental_schedules_over_the_joint_step_match_the_oracle(tmp_path, pr
             ref_losses.append(float(ref_step.joint_step(ip, tp, images, ids, mask, TAU, opt, n_layers=CFG["num_hidden_layers"],
                                                         n_heads=CFG["num_attention_heads"])))
     got = [v for _, v, _ in tr.writer.scalars("train/Loss")]
-    assert last == 5 and np.allclose(got, ref_losses, rtol=1e-3), (got, ref_losses)
+    assert last == 5 and np.allclose(got, ref_losses, rtol=2e-4), (got, ref_losses)
+    vb = list(val)
+    _, _, y_score = tr._eval_loop(vb, crit, 1, "val")
+    assert np.abs(y_score - _oracle_val_scores(ip, tp, engine, tr, vb[0][0]).numpy()).max() < 1e-3
     # continual-learning reset on the encoders: with threshold 1 every entry below the largest change of its tensor is restored
     tr.model_copy()
     before = tr.optimizer.flat_p.clone()

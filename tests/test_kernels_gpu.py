@@ -173,6 +173,46 @@ def test_conv_bn_relu_fwd_bwd(cfg):
             close(sums, dxd.double().view(-1, C).sum(0).float(), tol=5e-5, what="dgrad column sums")
 
 
+@pytest.mark.parametrize("ratio", [0.0, 5.0, 50.0])
+def test_bn_gamma_gradient_on_post_relu_input(ratio):
+    """The BatchNorm gamma gradient taken from the weight gradient, dgamma = rstd * (<w, dW_raw> - mean * sum(dy)), at the network's
+    own operating point: the unit's input is post-ReLU (all positive, like every unit of the trunk), the gradient sits behind the
+    unit's own ReLU, and the running mean is `ratio` sigma away from the batch mean.  Against the direct sum dy * (z - mean) * rstd in
+    fp64: the north star's 1e-3 (measured 2-4e-7 in fp32 mode, 2-5e-6 in split-bf16: scripts/exp_dgamma.py).  The 2e-3 / 2e-2
+    allowances of the conv tests above are for their zero-mean random inputs, where the direct sum itself cancels."""
+    N, H, C, Ko, R = 16, 28, 128, 128, 3
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, C, H, H, generator=g).abs()
+    w = torch.randn(Ko, C, R, R, generator=g) / math.sqrt(C * R * R)
+    dy = torch.randn(N, Ko, H, H, generator=g) * (torch.rand(N, Ko, H, H, generator=g) > 0.5)
+    z = F.conv2d(x.double(), w.double(), padding=1)
+    sig = z.std(dim=(0, 2, 3))
+    rm = (z.mean(dim=(0, 2, 3)) + ratio * sig).float()
+    rv = (sig * sig).float()
+    rstd64 = 1.0 / torch.sqrt(rv.double() + 1e-5)
+    ref = (dy.double() * (z - rm.double()[None, :, None, None]) * rstd64[None, :, None, None]).sum(dim=(0, 2, 3))
+    gamma, beta = torch.ones(Ko, device=DEV), torch.zeros(Ko, device=DEV)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    w_cl = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    sc, sh, rstd = (torch.empty(Ko, device=DEV) for _ in range(3))
+    dw, dg, db = torch.empty(Ko, R, R, C, device=DEV), torch.empty(Ko, device=DEV), torch.empty(Ko, device=DEV)
+    if _split():
+        wsp = K.Planes.empty(Ko, R * R * C, device=DEV)
+        K.bn_fold_pl(w_cl, gamma, beta, rm.to(DEV), rv.to(DEV), 1e-5, Ko, R * R, C, C, wsp, sc, sh, rstd)
+        xp, dyp = K.split_planes(xd.view(-1, C)), K.split_planes(dyd.view(-1, Ko))
+        sumdy = K.colsum(dyp, torch.empty(Ko, device=DEV))
+        K.conv_bwd_params_pl(xp, dyp, w_cl, sc, rstd, rm.to(DEV), sumdy, dw, dg, db, False, N, H, H, C, Ko, R, R, 1, 1)
+    else:
+        ws = torch.empty(Ko, R, R, C, device=DEV)
+        K.bn_fold(w_cl, gamma, beta, rm.to(DEV), rv.to(DEV), 1e-5, Ko, R * R, C, C, ws, sc, sh, rstd)
+        sumdy = K.colsum(dyd.view(-1, Ko), torch.empty(Ko, device=DEV))
+        K.conv_bwd_params(xd, dyd, w_cl, sc, rstd, rm.to(DEV), sumdy, dw, dg, db, False, N, H, H, C, C, Ko, R, R, 1, 1)
+    err = float((dg.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-3, (ratio, err)
+    assert err < (5e-5 if _split() else 5e-6), (ratio, err)      # where the kernels actually are
+
+
 @pytest.mark.parametrize("gval", [0.0, 1e-30, 1e-6, 1e-3])
 def test_bn_gamma_gradient_does_not_divide_by_gamma(gval):
     """dgamma used to be sum(dy*(y_bn - beta)) / gamma — inf / NaN / 1e-2 errors for zero-init-residual or pruned

@@ -112,6 +112,39 @@ def test_max_emb_training_step_matches_oracle(tmp_path, monkeypatch):
         assert float((ps.cpu() - full).abs().max()) < 1e-5
 
 
+def test_max_emb_positive_only_with_ten_prompts_per_class(tmp_path, monkeypatch):
+    """The reference's NEW_PROMPTS operating point with `TRAIN_LOGIT_DIFF = False` (`Trainer.py:42-44`, `new_texts_prompts.py`):
+    10 prompts per group over 5 classes, positive-only logits — 2 x 5 x 10 = 100 prompt rows go through ONE max-over-prompts cosine
+    call.  Its backward keeps a [prompts][128] accumulator per wave in LDS and walks the prompts in chunks of 32: round 2 refused more
+    than 64 rows (`CXRK_ERR_UNSUPPORTED` from inside `loss.backward()`).  One training step against the oracle."""
+    monkeypatch.setattr(TR, "MAX_EMB", True)
+    monkeypatch.setattr(TR, "TRAIN_LOGIT_DIFF", False)
+    classes = list(CHEXPERT_COMPETITION_CLASSES)
+    prompts = {c: {"positive": [f"finding number {i} suggesting {c}" for i in range(10)],
+                   "negative": [f"statement {i} excludes {c}" for i in range(10)]} for c in classes}
+    tr = TR.Trainer(False, prompts, classes, "standard", 1e-3, DEV, TR.ScalarWriter(str(tmp_path / "run")), bert_encoder=_engine())
+    syn.fill_module_(tr.image_adapter, "image_adapter.")
+    syn.fill_module_(tr.text_adapter, "text_adapter.")
+    ip = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in tr.image_adapter.state_dict().items()}
+    tp = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in tr.text_adapter.state_dict().items()}
+    pos = [tr.bert_encoder.get_embeddings_from_prompt(prompts[c]["positive"], normalize=False, verbose=False).cpu() for c in classes]
+    bert_out = torch.stack([p for p in pos for _ in (0, 1)])          # positive-only: both rows of a class hold its positive prompts
+    assert bert_out.shape == (10, 10, 128)
+    opt = torch.optim.Adam(list(tp.values()) + list(ip.values()), lr=1e-3)
+    train, _, _ = TR.Trainer.synthetic_loaders(200, 8, 8, batch_size=200, shuffle=False)
+    e, l = next(iter(train))
+    tr.train([(e, l)], nn.BCEWithLogitsLoss(), epoch=1)
+    opt.zero_grad()
+    ref = nn.functional.binary_cross_entropy_with_logits(ref_step.adapter_logits_max_emb(ip, tp, e, bert_out, diff=False), l)
+    ref.backward()
+    opt.step()
+    got = tr.writer.scalars("train/Loss")[0][1]
+    assert abs(got - float(ref)) < 1e-5, (got, float(ref))
+    for mod, ref_p in ((tr.image_adapter, ip), (tr.text_adapter, tp)):
+        for k, v in mod.state_dict().items():
+            assert float((v.cpu() - ref_p[k].detach()).abs().max() / ref_p[k].detach().abs().max()) < 1e-4, k
+
+
 def ref_loss_cos(x, y):
     from oracle import ref_loss
     return ref_loss.pairwise_cosine_similarity(x, y)
@@ -140,7 +173,7 @@ def test_class_incremental_and_weight_reset(tmp_path):
     # myCL weight reset (Trainer.py:1556-1587): snapshot, one step, restore small updates
     tr.model_copy()
     before = [p.detach().cpu().clone() for p in tr.image_adapter.parameters()]
-    tr._train_step(embs, labels, classes, crit)
+    tr._train_step((embs, labels), classes, crit)
     after = [p.detach().cpu().clone() for p in tr.image_adapter.parameters()]
     tr.myIncremental(0.4, 1)
     n_ref = 0
