@@ -98,7 +98,8 @@ class JointContrastiveTrainer:
         encoder's stages from the back (60 / 28 / 5 / 1 MB) under the layers in front of them; what is left (nothing, when every
         tag fired) is reduced after `backward()` returns.  Precondition, asserted: each encoder runs ONCE per step inside
         `forward_loss` — a second call of an encoder in the same graph would have its range reduced before the second
-        contribution was accumulated."""
+        contribution was accumulated.  A rank that raises inside `backward()` after a range was started leaves its peers inside that
+        collective, as any failure of one data-parallel rank does: the job has to be torn down (torchrun / the RCCL watchdog)."""
         self.optimizer.zero_grad()
         if self.world > 1 and self._spans:
             works, fired = [], []

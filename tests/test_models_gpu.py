@@ -169,6 +169,43 @@ def test_image_model_forward_backward(golden_dir):
     assert not model(x.to(DEV)).requires_grad
 
 
+def test_batchnorm_calibration_matches_a_train_mode_pass(monkeypatch):
+    """`ImageModel.calibrate_batchnorm_` (synthetic-weight set-up of bench.py): after the call every BatchNorm's running statistics
+    are the statistics of its own input over the batch — batch mean and unbiased batch variance, the values a train-mode
+    `torch.nn.BatchNorm2d` with momentum 1 would store — with each unit then evaluated on those statistics to feed the next one.
+    Against the same walk through the CPU oracle, all 54 units."""
+    import torch.nn.functional as F
+    from oracle import ref_image
+    model = get_biovil_resnet(None)
+    syn.fill_module_(model)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).eval()
+    x = syn.synthetic_images(8, 64, seed=11)
+
+    def bn_train(p, name, t, training=False):
+        var, mean = torch.var_mean(t, dim=(0, 2, 3), unbiased=True)
+        p[name + ".running_mean"].copy_(mean)
+        p[name + ".running_var"].copy_(var)
+        return F.batch_norm(t, mean, var, p[name + ".weight"], p[name + ".bias"], training=False, eps=ref_image.BN_EPS)
+    monkeypatch.setattr(ref_image, "_bn", bn_train)
+    ref_image.image_model_forward(sd, x)                 # updates the running statistics in `sd` in place
+    before = {k: v.clone() for k, v in model.state_dict().items() if "running" in k}
+    model.calibrate_batchnorm_(x.to(DEV))
+    after = {k: v for k, v in model.state_dict().items() if "running" in k and ".fc." not in k}
+    assert len(after) == 2 * 54
+    worst = max((rel(v, sd[k]), k) for k, v in after.items())
+    assert worst[0] < (1e-3 if _cxr_lib.get_precision() == "fp32" else 3e-3), worst
+    assert not torch.equal(after["encoder.encoder.layer3.0.bn2.running_mean"], before["encoder.encoder.layer3.0.bn2.running_mean"])
+    again = {k: v.clone() for k, v in after.items()}
+    model.calibrate_batchnorm_(x.to(DEV))                # same batch -> same statistics (the pass does not depend on the old ones)
+    assert all(rel(v, again[k]) < 1e-5 for k, v in model.state_dict().items() if k in again)
+    monkeypatch.undo()
+    with torch.no_grad():                                # and the eval-mode forward uses them: parity with the oracle on the new buffers
+        emb = model(x.to(DEV))
+    ref = ref_image.image_model_forward({k: v.detach().cpu() for k, v in model.state_dict().items()}, x)
+    assert rel(emb, ref) < TOL
+
+
 def test_reference_pinned_image_fixtures_through_the_hip_path(golden_dir):
     """The vectors of g3_image.npz that were produced by the reference's OWN code (modules.MLP on `proj_patch_in`) and the
     oracle's trunk checksums go through the HIP kernels directly, not only through the oracle."""
@@ -382,22 +419,22 @@ def test_joint_step_two_streams_equals_one_stream():
 
 # ------------------------------------------------------------------------------------------------ BASELINE config 1
 def test_zero_shot_engine_config1():
-    """ZERO_JOINT_BOUNDS-style zero-shot at BASELINE.json configs[0]'s size: 64 synthetic 224x224 images x 5 CheXpert class prompt
-    sets through ImageTextInferenceEngine vs the CPU oracle (trash/lower_bound_mcs.py:79-117)."""
+    """ZERO_JOINT_BOUNDS-style zero-shot at BASELINE.json configs[0]'s size and models: 64 synthetic 224x224 images x 5 CheXpert class
+    prompt sets through ImageTextInferenceEngine — full ResNet-50 and the full 12-layer / 768-hidden CXR-BERT configuration — vs the
+    CPU oracle (trash/lower_bound_mcs.py:79-117)."""
     from incremental_multimodal_medical_learning_ii_amd.DataRetrieval import CHEXPERT_COMPETITION_CLASSES, create_prompts
     from incremental_multimodal_medical_learning_ii_amd.health_multimodal.image import ImageInferenceEngine
     from incremental_multimodal_medical_learning_ii_amd.health_multimodal.image.data.transforms import create_chest_xray_transform_for_inference
     from incremental_multimodal_medical_learning_ii_amd.health_multimodal.text import SyntheticTokenizer, TextInferenceEngine
     from incremental_multimodal_medical_learning_ii_amd.health_multimodal.vlp import ImageTextInferenceEngine
     from oracle import ref_image, ref_loss, ref_text
-    cfg = CXRBertConfig(vocab_size=2048, hidden_size=128, num_attention_heads=2, intermediate_size=256,
-                        num_hidden_layers=2, max_position_embeddings=32)
+    cfg = CXRBertConfig()                                  # configuration_cxrbert.py:11-22: 12 layers, 12 heads, hidden 768, vocab 30522
     tm, im = CXRBertModel(cfg).eval(), get_biovil_resnet(None).eval()
     syn.fill_module_(tm)
     syn.fill_module_(im)
     isd = {k: v.clone() for k, v in im.state_dict().items()}
     tsd = {k: v.clone() for k, v in tm.state_dict().items()}
-    tok = SyntheticTokenizer(2048)
+    tok = SyntheticTokenizer(cfg.vocab_size)
     eng = ImageTextInferenceEngine(ImageInferenceEngine(im.to(DEV), create_chest_xray_transform_for_inference(512, 480)),
                                    TextInferenceEngine(tok, tm.to(DEV)))
     classes = list(CHEXPERT_COMPETITION_CLASSES)
@@ -409,7 +446,7 @@ def test_zero_shot_engine_config1():
     txt_ref = []
     for c in classes:
         t = tok.batch_encode_plus([p.rstrip("!?.") for p in prompts[c]["positive"]])
-        txt_ref.append(ref_text.cxrbert_projected(tsd, t.input_ids, t.attention_mask, 2, 2).mean(0))
+        txt_ref.append(ref_text.cxrbert_projected(tsd, t.input_ids, t.attention_mask, cfg.num_hidden_layers, cfg.num_attention_heads).mean(0))
     ref = ref_loss.zero_shot_scores(img_ref, torch.stack(txt_ref))
     assert rel(scores, ref) < TOL, rel(scores, ref)
     top2 = ref.topk(2, dim=1).values
