@@ -69,6 +69,11 @@ int cxrk_colsum(const float* X, long ldx, long rows, int cols, float* out, float
                 size_t ws_bytes, hipStream_t stream);
 int cxrk_colsum_pl(const void* X, long ldx, long plane, long rows, int cols, float* out, float alpha, int accumulate, float* ws,
                    size_t ws_bytes, hipStream_t stream);
+/* out[cols] = alpha * sum_rows (X[r][c] - mean[c])^2, X fp32 (plane == 0) or planes (plane > 0); ws as for cxrk_colsum.  The second
+ * pass of the batch variance `torch.nn.BatchNorm2d` stores in train mode (momentum 1): `ImageModel.calibrate_batchnorm_`, which
+ * gives synthetic weights statistics that match their activations (the reference only loads trained weights, model.py:117-118). */
+int cxrk_colvar(const void* X, long ldx, long plane, long rows, int cols, const float* mean, float* out, float alpha, float* ws,
+                size_t ws_bytes, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * conv_bn_act — torchvision Bottleneck conv + eval-mode BatchNorm + ReLU (+ residual) as used by

@@ -511,11 +511,14 @@ class Trainer:
                             self.writer.add_scalar("max-mean-comparison/" + tag, v, getattr(self, ctr))
                 else:
                     cos = Fh.pairwise_cosine_similarity(new_embs, pm)
+                # the fused loss + gradient kernel serves `nn.BCEWithLogitsLoss` with reduction "mean" (the reference's criterion) or
+                # "sum"; per-element weights, pos_weight, reduction "none" or any other criterion module are applied to the logits
+                # tensor as the caller's module defines them
                 fused = (type(criterion) is nn.BCEWithLogitsLoss and criterion.weight is None
-                         and criterion.pos_weight is None and criterion.reduction == "mean" and not self.change_labels)
+                         and criterion.pos_weight is None and criterion.reduction in ("mean", "sum") and not self.change_labels)
                 if fused:
                     lab = labels if labels.dim() == 2 else labels.unsqueeze(1)
-                    loss, logits = Fh.posneg_bce_loss(cos, lab, TRAIN_LOGIT_DIFF)
+                    loss, logits = Fh.posneg_bce_loss(cos, lab, TRAIN_LOGIT_DIFF, criterion.reduction)
                     if labels.dim() == 1:
                         logits = logits.reshape(-1)
                     return logits, loss, cos
@@ -563,11 +566,14 @@ class Trainer:
         n = embs.shape[0]
         lo, hi = self._shard(n) if self.world > 1 else (0, n)
         self.optimizer.zero_grad()
-        embs = embs[lo:hi].to(self.device, non_blocking=True)
-        labels = labels[lo:hi].to(self.device, non_blocking=True)
-        new_embs = self.image_adapter(embs) if self._has_img else embs
-        logits, loss, _ = self._logits_and_loss(new_embs, labels, class_names, criterion, use_grad=True)
-        loss.backward()
+        if hi > lo:
+            embs = embs[lo:hi].to(self.device, non_blocking=True)
+            labels = labels[lo:hi].to(self.device, non_blocking=True)
+            new_embs = self.image_adapter(embs) if self._has_img else embs
+            logits, loss, _ = self._logits_and_loss(new_embs, labels, class_names, criterion, use_grad=True)
+            loss.backward()
+        else:   # a ragged last batch with fewer rows than ranks: this rank contributes nothing, but takes part in the collectives
+            loss = torch.zeros((), dtype=torch.float32, device=self.device)
         if self.world > 1:
             # mean over the GLOBAL batch = sum over ranks of (rows of the shard / rows of the batch) x shard mean
             import torch.distributed as dist
@@ -623,7 +629,8 @@ class Trainer:
 
     def train_class_incremental(self, train_loader, criterion, epoch, CONTINUAL_LEARNING=None, threshold=None,
                                 current_task=None, last_batch=0, actual_task=None):
-        """One epoch on the single label column `current_task` (`Trainer.py:608-680`); returns the running iteration."""
+        """One epoch on the single label column `current_task` (`Trainer.py:608-680`); returns the running iteration.  (Joint-encoder
+        mode: the InfoNCE step has no label columns — the task is defined by what its loader yields, `current_task` only numbers it.)"""
         batch_idx = last_batch
         self._set_mode(True)
         cl = CONTINUAL_LEARNING == "myCL" and actual_task is not None and actual_task > 1
@@ -643,7 +650,8 @@ class Trainer:
 
     def train_class_more_labels_incremental(self, train_loader, criterion, epoch, CONTINUAL_LEARNING=None, threshold=None,
                                             current_task=None, last_batch=0, actual_task=None):
-        """One epoch on label columns `[:current_task+1]` (`Trainer.py:682-756`); returns the running iteration."""
+        """One epoch on label columns `[:current_task+1]` (`Trainer.py:682-756`); returns the running iteration.  (Joint-encoder mode:
+        as in `train_class_incremental`.)"""
         batch_idx = last_batch
         self._set_mode(True)
         cl = CONTINUAL_LEARNING == "myCL" and actual_task is not None and actual_task > 1
@@ -811,3 +819,11 @@ class Trainer:
                 if not isinstance(sd, dict) or not all(isinstance(v, torch.Tensor) for v in sd.values()):
                     raise ValueError(f"{path}: expected a state dict of tensors (see INTEGRATION.md, 'Adapter checkpoints')")
                 mod.load_state_dict(sd)
+        if self._joint is not None:   # the encoders `save` wrote in joint mode; the flat parameter buffer is updated in place
+            for mod, name in ((self.image_model, 'image_model.pt'), (self.bert_encoder.model, 'text_model.pt')):
+                sd = torch.load(os.path.join(self.writer.log_dir, name), map_location="cpu", weights_only=True)
+                with torch.no_grad():
+                    own = mod.state_dict()
+                    for k, v in sd.items():
+                        own[k].copy_(v)
+            self._bert_cache.clear()

@@ -26,6 +26,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_colsum_pl": (I, [P, L, L, L, I, P, F, I, P, Z, P]),
     "cxrk_colsum_ws_bytes": (Z, [L, I]),
     "cxrk_colsum": (I, [P, L, L, I, P, F, I, P, Z, P]),
+    "cxrk_colvar": (I, [P, L, L, L, I, P, P, F, P, Z, P]),
     "cxrk_bn_fold": (I, [P, P, P, P, P, F, I, I, I, I, P, P, P, P, P]),
     "cxrk_conv_bn_act_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "cxrk_bn_fold_pl": (I, [P, P, P, P, P, F, I, I, I, I, P, L, P, P, P, P]),

@@ -110,6 +110,28 @@ __global__ void colsum_partial_kernel(const float* __restrict__ X, long ldx, lon
   for (; r < r1; ++r) s0 += X[r * ldx + col];
   part[(long)blockIdx.y * cols + col] = (s0 + s1) + (s2 + s3);
 }
+// Stage 1 of the column sum of squared deviations sum_r (x[r][c] - mean[c])^2 (the second pass of a two-pass variance): fp32 (plane
+// == 0) or planes input, one column per thread, four rows in flight.  Used by the BatchNorm calibration pass only.
+__global__ void colvar_partial_kernel(const float* __restrict__ X, const unsigned short* __restrict__ Xp, long ldx, long plane, long rows,
+                                      int cols, int rows_per, const float* __restrict__ mean, float* __restrict__ part) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= cols) return;
+  const long r0 = (long)blockIdx.y * rows_per;
+  const long r1 = min(rows, r0 + rows_per);
+  const float m = mean[col];
+  auto val = [&](long r) {
+    if (Xp) return __builtin_bit_cast(float, (unsigned)Xp[r * ldx + col] << 16) + __builtin_bit_cast(float, (unsigned)Xp[plane + r * ldx + col] << 16);
+    return X[r * ldx + col];
+  };
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  long r = r0;
+  for (; r + 3 < r1; r += 4) {
+    const float a = val(r) - m, b = val(r + 1) - m, c = val(r + 2) - m, d = val(r + 3) - m;
+    s0 = fmaf(a, a, s0); s1 = fmaf(b, b, s1); s2 = fmaf(c, c, s2); s3 = fmaf(d, d, s3);
+  }
+  for (; r < r1; ++r) { const float a = val(r) - m; s0 = fmaf(a, a, s0); }
+  part[(long)blockIdx.y * cols + col] = (s0 + s1) + (s2 + s3);
+}
 __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int cols, float* __restrict__ out,
                                     float alpha, int accumulate) {
   const int col = blockIdx.x * 256 + threadIdx.x;
@@ -197,6 +219,25 @@ extern "C" int cxrk_colsum_pl(const void* X, long ldx, long plane, long rows, in
                      static_cast<const unsigned short*>(X), ldx, plane, rows, cols, rows_per, ws);
   CXRK_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, stream, ws, nparts, cols, out, alpha, accumulate);
+  CXRK_LAUNCH_CHECK();
+  return CXRK_OK;
+}
+
+// out[c] = alpha * sum_r (X[r][c] - mean[c])^2; X fp32 (plane == 0) or planes (plane > 0: hi at X, lo `plane` elements behind).
+extern "C" int cxrk_colvar(const void* X, long ldx, long plane, long rows, int cols, const float* mean, float* out, float alpha,
+                           float* ws, size_t ws_bytes, hipStream_t stream) {
+  CXRK_CHECK_ARG(X && mean && out && rows > 0 && cols > 0 && plane >= 0);
+  int nparts = (int)((rows + 511) / 512);
+  if (nparts > 512) nparts = 512;
+  if (nparts < 1) nparts = 1;
+  if (ws == nullptr || ws_bytes < (size_t)nparts * cols * sizeof(float)) return CXRK_ERR_WS;
+  const int rows_per = (int)((rows + nparts - 1) / nparts);
+  nparts = (int)((rows + rows_per - 1) / rows_per);
+  hipLaunchKernelGGL(colvar_partial_kernel, dim3(ceil_div(cols, 256), nparts), dim3(256), 0, stream,
+                     plane ? nullptr : static_cast<const float*>(X), plane ? static_cast<const unsigned short*>(X) : nullptr, ldx, plane, rows,
+                     cols, rows_per, mean, ws);
+  CXRK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, stream, ws, nparts, cols, out, alpha, 0);
   CXRK_LAUNCH_CHECK();
   return CXRK_OK;
 }

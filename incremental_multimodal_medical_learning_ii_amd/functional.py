@@ -159,24 +159,32 @@ def group_mean(x: torch.Tensor, groups: int, n: int) -> torch.Tensor:
 
 
 class _PosNegBCE(torch.autograd.Function):
-    """cos [B,2C] -> scalar mean BCE-with-logits of (cos_pos - cos_neg); gradient computed in the same pass."""
+    """cos [B,2C] -> scalar BCE-with-logits of (cos_pos - cos_neg), mean (scale 1) or sum (scale B*C) over the B*C logits; the
+    gradient is computed in the same pass."""
 
     @staticmethod
-    def forward(ctx, cosv, labels, diff):
+    def forward(ctx, cosv, labels, diff, scale):
         logits, dcos, loss = K.bce_posneg_fwd_bwd(cosv.detach().contiguous(), labels, diff=diff, need_grad=True)
         ctx.save_for_backward(dcos)
+        ctx.scale = float(scale)
         ctx.mark_non_differentiable(logits)
+        if scale != 1.0:
+            loss = K.scale_mask(loss.reshape(1), alpha=float(scale)).reshape(())
         return loss, logits
 
     @staticmethod
     def backward(ctx, gloss, _glogits):
         (dcos,) = ctx.saved_tensors
-        return K.scale_mask(dcos, alpha_dev=gloss.reshape(()).contiguous()), None, None
+        return K.scale_mask(dcos, alpha_dev=gloss.reshape(()).contiguous(), alpha=ctx.scale), None, None, None
 
 
-def posneg_bce_loss(cosv: torch.Tensor, labels: torch.Tensor, diff: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(loss, logits).  cos column 2c = positive prompt of class c, 2c+1 = negative."""
-    return _PosNegBCE.apply(cosv, labels, diff)
+def posneg_bce_loss(cosv: torch.Tensor, labels: torch.Tensor, diff: bool = True, reduction: str = "mean") -> Tuple[torch.Tensor, torch.Tensor]:
+    """(loss, logits).  cos column 2c = positive prompt of class c, 2c+1 = negative.  `reduction`: "mean" (`nn.BCEWithLogitsLoss()`,
+    the reference's criterion, ZERO_JOINT_BOUNDS.py:36) or "sum"."""
+    if reduction not in ("mean", "sum"):
+        raise ValueError(f"posneg_bce_loss: reduction must be 'mean' or 'sum', got {reduction!r}")
+    n_logits = cosv.shape[0] * (cosv.shape[1] // 2)
+    return _PosNegBCE.apply(cosv, labels, diff, 1.0 if reduction == "mean" else float(n_logits))
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -235,21 +235,6 @@ def _unit_params_bwd(i, s, fold, p, bufs, x, dy, sumdy, N, H, W, sink: GradSink,
         K.conv_bwd_params(x, dy, *args, s.cin, s.cpad, s.cout, s.k, s.k, s.stride, s.pad)
 
 
-_side_streams: dict = {}
-
-
-def _wgrad_stream(dev) -> Optional["torch.cuda.Stream"]:
-    """The side stream the parameter-gradient launches of the backward run on (CXRK_WGRAD_STREAM=1; experiment, see `_backward`)."""
-    import os
-    if os.environ.get("CXRK_WGRAD_STREAM", "0") != "1" or dev.type != "cuda":
-        return None
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    st = _side_streams.get(key)
-    if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=dev)
-    return st
-
-
 def _dgrad(i, s, fold, dy, residual, relu, N, H, W, pl, want_sums):
     """Data gradient of unit i, masked by `relu` (planes mode: the bit mask of the tensor the gradient flows into; fp32 mode:
     that tensor itself).  want_sums: also the column sums of the result (-> (dx, sums[C]))."""
@@ -282,30 +267,14 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
     in place: "head" after the projector and layer4, "layer3", "layer2", and "stem" (layer1 + stem) at the end — only while no
     gradient of the stage had to be returned to autograd as a fresh tensor."""
     fold, x0, stem, idx, pooled, binfo, last, pj1, mp, w3p, (N, H, W, Hs, Ws, h, w), pl = state
-    # Experiment (CXRK_WGRAD_STREAM=1): the data-gradient chain is the critical path of this backward; the parameter gradients of a
-    # unit (weight gradient GEMM, its slab reduction, the BatchNorm gamma / beta kernels) depend on it but nothing in the chain
-    # depends on them, so they run on a side stream and fill the tails of the chain's launches.  Tensors they read are marked as in
-    # use by that stream (the caching allocator then does not hand their memory out again before the side stream has passed).
-    main = torch.cuda.current_stream(p[0].device) if p[0].is_cuda else None
-    side = _wgrad_stream(p[0].device) if p[0].is_cuda else None
-
     def params_bwd(i, s_, x_, dy_, sum_, N_, H_, W_, pl_):
-        if side is None:
-            return _unit_params_bwd(i, s_, fold, p, bufs, x_, dy_, sum_, N_, H_, W_, sink, pl_)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            _unit_params_bwd(i, s_, fold, p, bufs, x_, dy_, sum_, N_, H_, W_, sink, pl_)
-        for t in (x_, dy_, sum_):
-            if t is not None:
-                (t.t if isinstance(t, Planes) else t).record_stream(side)
+        # (Running these launches on a side stream, beside the data-gradient chain they depend on but which does not depend on them,
+        #  was measured in round 3: 158.74 against 158.66 / 158.94 ms per step, bit-identical results — the GPU is not idle at kernel
+        #  tails, the step is the sum of its kernels' times.  Not kept.)
+        _unit_params_bwd(i, s_, fold, p, bufs, x_, dy_, sum_, N_, H_, W_, sink, pl_)
 
     def report(stage):
-        if on_grads_ready is None:
-            return
-        if side is None:
-            return on_grads_ready(stage)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):     # the range's all-reduce is ordered behind BOTH streams' gradient writes
+        if on_grads_ready is not None:
             on_grads_ready(stage)
 
     ns = len(specs)
@@ -392,8 +361,6 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
     params_bwd(0, specs[0], x0, ds, sum_s, N, H, W, False)   # fp32 operands (the image), split on the fly in split_bf16 mode
     if on_grads_ready is not None and all(r is None for r in sink.ret):
         report("stem")
-    if side is not None:
-        main.wait_stream(side)      # autograd / the optimiser continue on the main stream
     return sink.ret
 
 
@@ -521,10 +488,12 @@ def calibrate_batchnorm_(specs, blocks, params, bufs, x: torch.Tensor) -> None:
         one, zero = torch.ones(s.cout, device=dev), torch.zeros(s.cout, device=dev)
         fold_unit(i, s, one, zero, zero, one)
         raw, _ = _conv(i, s, fold, xin, None, False, N, h, w, pl, want_mask=False)
-        r = (raw.float() if pl else raw).reshape(-1, s.cout)
-        var, mean = torch.var_mean(r.double(), dim=0, unbiased=True)
-        b[2 * i].copy_((mean * k).float())
-        b[2 * i + 1].copy_((var * k * k).float().clamp_min(1e-12))
+        r = raw.view(-1, s.cout)                       # [pixels, channels], fp32 or planes
+        rows = r.shape[0]
+        # two-pass batch statistics on the path's own reductions; the identity fold scaled the output by 1 / k
+        K.colsum(r, b[2 * i], alpha=1.0 / rows)                                       # mean of raw
+        K.colvar(r, b[2 * i], b[2 * i + 1], alpha=k * k / max(1, rows - 1))           # unbiased variance of k * raw
+        K.scale_mask(b[2 * i], alpha=k, out=b[2 * i])                                 # mean of k * raw
         del raw, r
         fold_unit(i, s, p[3 * i + 1], p[3 * i + 2], b[2 * i], b[2 * i + 1])
         return _conv(i, s, fold, xin, residual, relu, N, h, w, pl, want_mask=want_mask)[0]

@@ -416,6 +416,25 @@ def colsum(x: torch.Tensor, out: torch.Tensor, alpha: float = 1.0, accumulate: b
     return out
 
 
+def colvar(x, mean: torch.Tensor, out: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """out[c] = alpha * sum_r (x[r, c] - mean[c])^2 for a 2-D fp32 tensor or Planes (second pass of a two-pass batch variance)."""
+    lib = _lib.load()
+    if isinstance(x, Planes):
+        xp, ldx, xpl = _pl2d(x, "colvar.x")
+        rows, cols = x.shape
+    else:
+        x, ldx = _rowmajor2d(x, "colvar.x")
+        xp, xpl = x.data_ptr(), 0
+        rows, cols = x.shape
+    _chk(mean, "colvar.mean")
+    _chk(out, "colvar.out")
+    if mean.numel() != cols or out.numel() != cols or not mean.is_contiguous() or not out.is_contiguous():
+        raise ValueError(f"colvar: mean / out must be contiguous with {cols} elements")
+    ws = workspace(lib.cxrk_colsum_ws_bytes(rows, cols), out.device)
+    check(lib.cxrk_colvar(xp, ldx, xpl, rows, cols, _p(mean), _p(out), float(alpha), _p(ws), ws.numel() * 4, _stream()), "cxrk_colvar")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # image encoder pieces (NHWC)
 # ----------------------------------------------------------------------------------------------------------------

@@ -98,6 +98,11 @@ def test_incremental_schedules_over_the_joint_step_match_the_oracle(tmp_path, pr
     assert "Accuracy" in m
     tr.save()
     assert os.path.exists(os.path.join(tr.writer.log_dir, "image_model.pt")) and os.path.exists(os.path.join(tr.writer.log_dir, "text_model.pt"))
+    flat = tr.optimizer.flat_p.detach().clone()
+    with torch.no_grad():
+        tr.optimizer.flat_p.add_(1.0)                     # every parameter of both encoders lives in this buffer
+    tr.load()
+    assert torch.equal(tr.optimizer.flat_p, flat)
     # ---- class-incremental: 5 tasks over the contiguous fifths ("class-pos-neg"), MORE_LABELS form, then the single-label form
     # (with `Trainer.OPTIM = "sgd"`, the reference's other optimiser, Trainer.py:176-178: updates proportional to the gradient, so
     #  the two trajectories stay together and the comparison is tight)

@@ -68,13 +68,25 @@ def test_joint_train_val_test_match_oracle(tmp_path):
     m = tr.val(val, crit, epoch=1, epochs=1)
     assert {"Accuracy", "F1-macro score", "F1-weighted score"} <= set(m)
     assert "Accuracy" in tr.test(test, crit, epoch=1, epochs=1)
-    # a criterion the fused path does not recognise is applied to the logits as given
-    tr2, _, _ = _trainer(tmp_path / "b")
+    # reduction="sum" runs on the fused loss + gradient kernel too: loss and the update against torch
+    tr2, _, _ = _trainer(tmp_path / "b", lr=1e-5)
     ip2, tp2, _ = _oracle_state(tr2, classes, prompts)
+    opt2 = torch.optim.Adam(list(tp2.values()) + list(ip2.values()), lr=1e-5)
     tr2.train([(e[:32], l[:32])], nn.BCEWithLogitsLoss(reduction="sum"), epoch=1)
     lg = ref_step.adapter_logits(ip2, tp2, e[:32], bert_out)
     ref = nn.functional.binary_cross_entropy_with_logits(lg, l[:32], reduction="sum")
     assert abs(tr2.writer.scalars("train/Loss")[0][1] - float(ref)) / float(ref) < 1e-5
+    ref.backward()
+    opt2.step()
+    for k, v in tr2.image_adapter.state_dict().items():
+        assert float((v.cpu() - ip2[k].detach()).abs().max() / ip2[k].detach().abs().max()) < 1e-4, k
+    # a criterion the fused kernel does not serve (pos_weight) is applied to the logits tensor as the caller's module defines it
+    tr3, _, _ = _trainer(tmp_path / "c")
+    ip3, tp3, _ = _oracle_state(tr3, classes, prompts)
+    pw = torch.tensor([1.0, 2.0, 0.5, 3.0, 1.5])
+    tr3.train([(e[:32], l[:32])], nn.BCEWithLogitsLoss(pos_weight=pw.to(DEV)), epoch=1)
+    ref3 = nn.functional.binary_cross_entropy_with_logits(ref_step.adapter_logits(ip3, tp3, e[:32], bert_out), l[:32], pos_weight=pw)
+    assert abs(tr3.writer.scalars("train/Loss")[0][1] - float(ref3)) / float(ref3) < 1e-5
 
 
 def test_max_emb_training_step_matches_oracle(tmp_path, monkeypatch):
