@@ -581,6 +581,10 @@ def main():
                                                 "2 extra steps with both encoders on ONE stream (in the timed region their kernels "
                                                 "co-run on two streams, so a per-launch event bracket would cover both)"),
                                    "avg_launch_ms": d["ms"] / d["launches"],
+                                   "binding_roof_frac": d["floor_ms"] / d["ms"],
+                                   "binding_roof_note": "sum over this instantiation's launches of max(FLOPs / MFMA peak, algorithmic bytes / HBM "
+                                                        "peak) / their time: each launch priced against ITS binding roof (the instantiation mixes "
+                                                        "HBM-bound K = 64 layers with MFMA-bound K = 2304 ones; `frac` prices them all against one roof)",
                                    "gflop_per_launch": d["flops"] / d["launches"] / 1e9,
                                    "algorithmic_mb_per_launch": d["bytes"] / d["launches"] / 1e6,
                                    "other_bound": {"bound": "mfma" if hbm else "hbm", "achieved": tflops if hbm else gbps,
@@ -588,6 +592,7 @@ def main():
                                                    "unit": "TFLOP/s" if hbm else "GB/s",
                                                    "frac": frac_mfma if hbm else frac_hbm, "note": mfma_note if hbm else ""},
                                    "family": {"kernel": "gemm_*_kernel<*> (all MFMA mainloop instantiations)",
+                                              "binding_roof_frac": sum(v["floor_ms"] for v in summ.values()) / tot_ms,
                                               "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
                                               "algorithmic_gbps": tot_by / (tot_ms * 1e-3) / 1e9,
                                               "ms_per_step": tot_ms / prof_steps}}

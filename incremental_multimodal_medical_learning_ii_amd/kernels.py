@@ -126,9 +126,11 @@ class LaunchProfiler:
     events and tagged with its kernel instantiation (the name rocprofv3 reports, scripts/pmc_summary_key.py), its algorithmic
     FLOPs (2*M*N*K) and its algorithmic HBM bytes (every operand and side input read once, every output written once)."""
 
+    PEAK_BF16X3, PEAK_F32, PEAK_HBM = 2500e12 / 3.0, 157.3e12, 8.0e12   # /opt/skills/guides/MI355X_MICROARCH.md (bench.py's constants)
+
     def __init__(self):
         self.on = False
-        self.rows = []  # (key, flops, bytes, start_event, end_event)
+        self.rows = []  # (key, flops, bytes, start_event, end_event, kernel launches inside the bracket)
 
     def start(self):
         self.on, self.rows = True, []
@@ -149,11 +151,14 @@ class LaunchProfiler:
         """{kernel: {"launches", "flops", "bytes", "ms"}} — call after torch.cuda.synchronize()."""
         out = {}
         for key, flops, nbytes, a, b, sub in self.rows:
-            d = out.setdefault(key, {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0})
+            d = out.setdefault(key, {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0, "floor_ms": 0.0})
             d["launches"] += sub
             d["flops"] += flops
             d["bytes"] += nbytes
             d["ms"] += a.elapsed_time(b)
+            # the launch's own binding roof: max(FLOPs / MFMA peak of its mainloop, algorithmic bytes / HBM peak)
+            peak = self.PEAK_BF16X3 if (key.startswith("gemm_pw") or key.startswith("gemm_x3")) else self.PEAK_F32
+            d["floor_ms"] += 1e3 * max(flops / peak, nbytes / self.PEAK_HBM)
         return out
 
 
