@@ -9,8 +9,9 @@ values and the restatement in `oracle/` is asserted against them first:
   G1  `health_multimodal/text/model/modelling_cxrbert.py`  CXRBertModel          (text encoder + head)
   G2  `models.py`                                           myMLP, myLinearModel  (adapters) + torch BCE/Adam
   G3  `health_multimodal/image/model/modules.py`            MLP                   (image projector)
-The ResNet-50 trunk (torchvision 0.10 absent), pairwise cosine (torchmetrics absent), InfoNCE and the
-encoder backward (not in the reference) are produced by the restatement alone: "parity unpinned".
+The ResNet-50 trunk cannot be checked against the reference's own torchvision 0.10 (absent): G7 checks the restatement against
+an independent third-party implementation of the same architecture (transformers.ResNetModel) instead.  Pairwise cosine
+(torchmetrics absent) and InfoNCE (not in the reference) are produced by the restatement alone: "parity unpinned".
 No reference source text is stored — only inputs, weights the build's own rule generated, and outputs.
 """
 from __future__ import annotations
@@ -284,10 +285,89 @@ def gen_g6():
     print("G6 written")
 
 
+def hf_resnet50_with_rule_weights(p):
+    """An INDEPENDENT implementation of the trunk's architecture: HuggingFace `transformers.ResNetModel` (bottleneck ResNet-50,
+    stride on the 3x3 convolution = torchvision's v1.5 layout that `resnet.py:73-80` instantiates), loaded with the same name-keyed
+    weights under its own parameter names.  torchvision 0.10 itself is absent here, so this is the closest
+    third-party pin available for the ResNet-50 restatement in oracle/ref_image.py."""
+    from transformers import ResNetConfig, ResNetModel
+    cfg = ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[256, 512, 1024, 2048], depths=[3, 4, 6, 3], layer_type="bottleneck",
+                       hidden_act="relu", downsample_in_first_stage=False, downsample_in_bottleneck=False)
+    model = ResNetModel(cfg).eval()
+    sd = {}
+
+    def bn(dst, src):
+        for suf in ("weight", "bias", "running_mean", "running_var"):
+            sd[f"{dst}.{suf}"] = p[f"{src}.{suf}"].detach().clone()
+
+    pre = "encoder.encoder."
+    sd["embedder.embedder.convolution.weight"] = p[pre + "conv1.weight"].detach().clone()
+    bn("embedder.embedder.normalization", pre + "bn1")
+    for li, nblk in enumerate(ref_image.LAYERS, start=1):
+        for b in range(nblk):
+            src, dst = f"{pre}layer{li}.{b}.", f"encoder.stages.{li - 1}.layers.{b}."
+            for k in (1, 2, 3):
+                sd[f"{dst}layer.{k - 1}.convolution.weight"] = p[f"{src}conv{k}.weight"].detach().clone()
+                bn(f"{dst}layer.{k - 1}.normalization", f"{src}bn{k}")
+            if b == 0:
+                sd[f"{dst}shortcut.convolution.weight"] = p[f"{src}downsample.0.weight"].detach().clone()
+                bn(f"{dst}shortcut.normalization", f"{src}downsample.1")
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and all("num_batches_tracked" in k for k in res.missing_keys), (res.unexpected_keys, res.missing_keys[:5])
+    return model
+
+
+def gen_g7():
+    """G7: the ResNet-50 trunk against an independent implementation (see `hf_resnet50_with_rule_weights`): stage outputs and the
+    gradients of a probe through the whole trunk."""
+    prm, buf = ref_image.image_param_shapes()
+    p = {k: syn.rule_tensor(k, s) for k, s in {**prm, **buf}.items()}
+    model = hf_resnet50_with_rule_weights(p)
+    x = syn.synthetic_images(2, 224, seed=27)
+    for q in model.parameters():
+        q.requires_grad_(True)
+    out = model(x, output_hidden_states=True)
+    hs = list(out.hidden_states)                       # [pooled stem, stage1, stage2, stage3, stage4]
+    assert len(hs) == 5 and hs[-1].shape == (2, 2048, 7, 7)
+    probe = torch.from_numpy(syn._normal("g7.probe", (2, 2048, 7, 7)))
+    (hs[-1] * probe).sum().backward()
+    # the restatement, same weights, same input, same probe
+    for k in p:
+        if p[k].dtype == torch.float32:
+            p[k].requires_grad_("running" not in k)
+    coll = []
+    patch = ref_image.resnet50_trunk(p, x, collect=coll)
+    (patch * probe).sum().backward()
+    worst = max(relerr(a, b) for a, b in zip(coll, hs))
+    hf_named = dict(model.named_parameters())
+    pairs = {"encoder.encoder.conv1.weight": "embedder.embedder.convolution.weight",
+             "encoder.encoder.bn1.weight": "embedder.embedder.normalization.weight",
+             "encoder.encoder.layer1.0.conv1.weight": "encoder.stages.0.layers.0.layer.0.convolution.weight",
+             "encoder.encoder.layer2.0.downsample.0.weight": "encoder.stages.1.layers.0.shortcut.convolution.weight",
+             "encoder.encoder.layer3.2.conv2.weight": "encoder.stages.2.layers.2.layer.1.convolution.weight",
+             "encoder.encoder.layer3.2.bn2.bias": "encoder.stages.2.layers.2.layer.1.normalization.bias",
+             "encoder.encoder.layer4.2.conv3.weight": "encoder.stages.3.layers.2.layer.2.convolution.weight",
+             "encoder.encoder.layer4.2.bn3.weight": "encoder.stages.3.layers.2.layer.2.normalization.weight"}
+    gworst = max(relerr(p[a].grad, hf_named[b].grad) for a, b in pairs.items())
+    print(f"G7 trunk: restatement vs transformers.ResNetModel: stage outputs rel err {worst:.2e}, probed gradients {gworst:.2e}")
+    assert worst < 1e-5 and gworst < 1e-4
+    rec = {"probe": np_(probe)}
+    for i, c in enumerate(hs):
+        rec[f"stage{i}_absmean"] = np.float32(c.abs().mean().item())
+        rec[f"stage{i}_sum"] = np.float64(c.double().sum().item())
+        rec[f"stage{i}_corner"] = np_(c[:, :4, :3, :3])
+    for a, b in pairs.items():
+        g = hf_named[b].grad
+        rec["g::" + a] = np_(g if g.numel() <= 40000 else g.flatten()[:40000])
+        rec["gnorm::" + a] = np.float64(g.double().norm().item())
+    np.savez_compressed(os.path.join(OUT, "g7_trunk_hf.npz"), **rec)
+    print("G7 written")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g7"]
     if "g1" in which:
         gen_g1()
     if "g2" in which:
@@ -298,3 +378,5 @@ if __name__ == "__main__":
         gen_g4_g5()
     if "g6" in which:
         gen_g6()
+    if "g7" in which:
+        gen_g7()

@@ -222,6 +222,11 @@ def test_reference_pinned_image_fixtures_through_the_hip_path(golden_dir):
         assert abs(float(st.double().sum()) - float(g[f"stage{i}_sum"])) / (float(g[f"stage{i}_absmean"]) * n) < 1e-5, i
         assert abs(float(st.abs().mean()) - float(g[f"stage{i}_absmean"])) / float(g[f"stage{i}_absmean"]) < TOL, i
         assert rel(st[:, :4, :3, :3], g[f"stage{i}_corner"]) < TOL, (i, rel(st[:, :4, :3, :3], g[f"stage{i}_corner"]))
+    # the same stage outputs as an independent ResNet-50 implementation computes them (transformers.ResNetModel, fixture G7)
+    h = np.load(f"{golden_dir}/g7_trunk_hf.npz")
+    for i, st in enumerate(stages):
+        assert abs(float(st.abs().mean()) - float(h[f"stage{i}_absmean"])) / float(h[f"stage{i}_absmean"]) < TOL, i
+        assert rel(st[:, :4, :3, :3], h[f"stage{i}_corner"]) < TOL, (i, rel(st[:, :4, :3, :3], h[f"stage{i}_corner"]))
 
 
 def test_image_model_rejects_cpu_and_bad_input():

@@ -77,6 +77,34 @@ def test_g3_image(golden_dir):
     assert rel(emb, g["emb"]) < 1e-5
 
 
+def test_g7_trunk_vs_independent_resnet(golden_dir):
+    """G7: stage outputs and probed gradients of the ResNet-50 trunk as computed by an INDEPENDENT implementation of the architecture
+    (HuggingFace transformers.ResNetModel, torchvision-v1.5 stride placement, same name-keyed weights; oracle/gen_golden.py::gen_g7).
+    The reference's own torchvision 0.10 is absent, so this is the pin available for `oracle/ref_image.resnet50_trunk`."""
+    g = np.load(f"{golden_dir}/g7_trunk_hf.npz")
+    prm, buf = ref_image.image_param_shapes()
+    p = {k: syn.rule_tensor(k, s) for k, s in {**prm, **buf}.items()}
+    for k, v in p.items():
+        if v.dtype == torch.float32:
+            v.requires_grad_("running" not in k)
+    coll = []
+    patch = ref_image.resnet50_trunk(p, syn.synthetic_images(2, 224, seed=27), collect=coll)
+    assert len(coll) == 5
+    for i, c in enumerate(coll):
+        assert abs(float(c.double().sum()) - float(g[f"stage{i}_sum"])) <= 1e-6 * float(g[f"stage{i}_absmean"]) * c.numel(), i
+        assert rel(c[:, :4, :3, :3], g[f"stage{i}_corner"]) < 1e-6, i
+    (patch * T(g["probe"])).sum().backward()
+    checked = 0
+    for k in g.files:
+        if k.startswith("g::"):
+            ref = T(g[k])
+            got = p[k[3:]].grad.flatten()[: ref.numel()].reshape(ref.shape) if ref.numel() != p[k[3:]].numel() else p[k[3:]].grad
+            assert rel(got, ref) < 1e-5, k
+            assert abs(float(p[k[3:]].grad.double().norm()) - float(g["gnorm::" + k[3:]])) / float(g["gnorm::" + k[3:]]) < 1e-6, k
+            checked += 1
+    assert checked == 8
+
+
 def test_g4_g5_heads(golden_dir):
     g = np.load(f"{golden_dir}/g4_infonce.npz")
     for tau in (1.0, 0.07):
