@@ -119,6 +119,41 @@ def test_g4_g5_heads(golden_dir):
     assert rel(sc, z["scores"]) < 1e-6 and torch.equal(sc.argmax(1), T(z["argmax"]))
 
 
+def test_cosine_and_infonce_against_independent_implementations():
+    """The two heads the reference holds no fixture for, against implementations that share no code with the restatement:
+    `pairwise_cosine_similarity` (torchmetrics is absent) vs scikit-learn's `cosine_similarity` (a pinned dependency of the reference,
+    requirements.txt), incl. its gradient by central differences in float64; `infonce` vs a numpy / scipy float64 evaluation of
+    (CE(S, diag) + CE(S^T, diag)) / 2 and its autograd gradient vs the closed form (softmax_row + softmax_col - 2 I) / (2 B tau)."""
+    from scipy.special import logsumexp, softmax
+    from sklearn.metrics.pairwise import cosine_similarity
+    g = torch.Generator().manual_seed(11)
+    x, y = torch.randn(37, 128, generator=g), torch.randn(10, 128, generator=g) * 3.0
+    assert rel(ref_loss.pairwise_cosine_similarity(x, y), torch.from_numpy(cosine_similarity(x.numpy(), y.numpy()))) < 1e-6
+    xd = x.double().requires_grad_(True)
+    w = torch.randn(37, 10, generator=g).double()
+    (ref_loss.pairwise_cosine_similarity(xd, y.double()) * w).sum().backward()
+    i, j, h = 5, 77, 1e-6
+    xp, xm = x.double().numpy().copy(), x.double().numpy().copy()
+    xp[i, j] += h
+    xm[i, j] -= h
+    fd = ((cosine_similarity(xp, y.double().numpy()) - cosine_similarity(xm, y.double().numpy())) * w.numpy()).sum() / (2 * h)
+    assert abs(float(xd.grad[i, j]) - fd) < 1e-6 * max(1.0, abs(fd))
+    for tau in (1.0, 0.07):
+        I, Tt = torch.randn(24, 128, generator=g).requires_grad_(True), torch.randn(24, 128, generator=g)
+        loss, S = ref_loss.infonce(I, Tt, tau)
+        In = I.detach().double().numpy() / np.linalg.norm(I.detach().double().numpy(), axis=1, keepdims=True)
+        Tn = Tt.double().numpy() / np.linalg.norm(Tt.double().numpy(), axis=1, keepdims=True)
+        Sn = In @ Tn.T / tau
+        ref = 0.5 * ((logsumexp(Sn, axis=1) - np.diag(Sn)).mean() + (logsumexp(Sn, axis=0) - np.diag(Sn)).mean())
+        assert abs(float(loss) - ref) < 2e-6 * max(1.0, abs(ref)) and np.abs(S.detach().numpy() - Sn).max() < 1e-4
+        loss.backward()
+        dS = (softmax(Sn, axis=1) + softmax(Sn, axis=0) - 2 * np.eye(24)) / (2 * 24)          # dL/dS
+        dIn = dS @ Tn / tau                                                                   # dL/d(normalised I)
+        nI = np.linalg.norm(I.detach().double().numpy(), axis=1, keepdims=True)
+        dI = (dIn - In * (In * dIn).sum(1, keepdims=True)) / nI                               # through x / |x|
+        assert np.abs(I.grad.numpy() - dI).max() < 1e-5 * np.abs(dI).max()
+
+
 def test_g6_similarity_map_and_max_emb(golden_dir):
     """G6: the similarity-map vectors are outputs of the reference's own `_get_similarity_map_from_embeddings` /
     `convert_similarity_to_image_size`; the oracle restatement and the product's host-side resize must reproduce them exactly."""
