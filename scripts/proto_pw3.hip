@@ -90,26 +90,28 @@ __global__ __launch_bounds__(256, 2) void kernel(const unsigned short* A, long l
   rd(A0, stage(0), PLANE_A, arow, lane);
   rd(Bc, stage(0) + 2 * PLANE_A, PLANE_B, bcol, lane);
   const int NK = (K + BK3 - 1) / BK3;
-  for (int t = 0; t < NK; ++t) {
+  // one K-tile: group 0 (rows 0-63) with the DMA of tile t + 2 into the stage tile t - 1 vacated (every wave passed tile t - 1's
+  // barrier), group 1 (rows 64-127) behind the K-tile's one barrier (tile t + 1 has landed everywhere, nobody reads tile t - 1's stage)
+  auto ktile = [&](int t, Frag& bcur, Frag& bnext) {
     unsigned char* st = stage(t);
     unsigned char* nx = stage(t + 1);
-    // group 0: rows 0-63.  The DMA of tile t + 2 goes into the stage tile t - 1 vacated (every wave passed tile t - 1's barrier)
     rd(A1, st, PLANE_A, arow + 64, lane);
     { const int k2 = (t + 2) * BK3; la.issue(k2, stage(t + 2), k2 < K); lb.issue(k2, stage(t + 2) + 2 * PLANE_A, k2 < K); }
     __builtin_amdgcn_sched_barrier(0);
-    pw_mfma12(acc[0], A0, Bc);
+    pw_mfma12(acc[0], A0, bcur);
     __builtin_amdgcn_sched_barrier(0);
-    // group 1: rows 64-127, behind the K-tile's one barrier: tile t + 1 has landed everywhere, nobody reads tile t's stage any more
     asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     rd(A0, nx, PLANE_A, arow, lane);
-    rd(Bn, nx + 2 * PLANE_A, PLANE_B, bcol, lane);
+    rd(bnext, nx + 2 * PLANE_A, PLANE_B, bcol, lane);
     __builtin_amdgcn_sched_barrier(0);
-    pw_mfma12(acc[1], A1, Bc);
+    pw_mfma12(acc[1], A1, bcur);
     __builtin_amdgcn_sched_barrier(0);
-    Bc = Bn;
-  }
+  };
+  int t = 0;
+  for (; t + 1 < NK; t += 2) { ktile(t, Bc, Bn); ktile(t + 1, Bn, Bc); }
+  if (t < NK) ktile(t, Bc, Bn);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 64);
