@@ -256,6 +256,16 @@ def secondary_metrics(args, dev, trainer, images, ids, mask, step_ms):
         dt = timed(lambda: trainer.image_model(x512), 3)
     out["embedding_precompute_512px_b64"] = {"images_per_sec": 64 / dt, "ms_per_batch": dt * 1e3}
     del x512
+    # (2b) the same joint step with the image encoder's BatchNorm in TRAIN mode (batch statistics + running-stat updates, the state the
+    # reference's constructor leaves the model in): separate statistics / normalisation / backward kernels around the same GEMMs
+    try:
+        trainer.image_model.train()
+        dt = timed(lambda: trainer.step(images, ids, mask), 3)
+        out["train_mode_batchnorm"] = {"ms_per_step": dt * 1e3, "images_per_sec": ids.shape[0] / dt,
+                                       "note": "ImageModel.train(): batch statistics (csrc/bn_train.hip); the headline runs the eval-mode "
+                                               "fold, the only mode the reference uses the encoder in"}
+    finally:
+        trainer.image_model.eval()
     # (3) ragged prompts (lengths ~U{8..32}, right-padded): same step, attention masked
     rid, rmask = syn.synthetic_tokens(ids.shape[0], ids.shape[1], seed=33, ragged=True)
     rid, rmask = rid.to(dev), rmask.to(dev)

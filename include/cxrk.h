@@ -148,6 +148,31 @@ int cxrk_spatial_mean_bwd(const float* dy, float* dx, int N, int P, int C, hipSt
 int cxrk_spatial_mean_bwd_pl(const float* dy, const float* add, void* dx, long dxplane, int N, int P, int C, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Train-mode BatchNorm2d around the convolutions (csrc/bn_train.hip): the mode the reference's `ImageModel` constructor leaves the
+ * model in (`self.train()`, health_multimodal/image/model/model.py:119) — batch statistics in the forward, running statistics updated
+ * with momentum, the batch-statistics terms in the backward (torch.nn.BatchNorm2d, training=True).  Tensors `void* p, long plane`:
+ * fp32 when plane == 0, split-bf16 planes otherwise; [rows = pixels][C], C % 8 == 0.
+ *   forward:   z = conv(x, w) (cxrk_conv_bn_act_fwd* with an identity fold); mean = colsum(z) / n; var = colvar(z, mean) / n;
+ *              cxrk_bn_train_fwd_coeffs -> scale = gamma rstd, shift = beta - mean scale, rstd (+ running statistics update when
+ *              rmean / rvar are given: r = (1 - momentum) r + momentum stat, variance unbiased);  cxrk_bn_apply: y = relu?(z scale +
+ *              shift + residual?), ReLU decision bits (byte [row][c / 8]) when mask != null.
+ *   backward:  dot = cxrk_coldot(dy, z) = sum_rows dy z;  cxrk_bn_train_bwd_coeffs -> dbeta (+)= sum dy, dgamma (+)= rstd (dot - mean
+ *              sum dy), and A, B, Cc with dz = A dy + B + Cc z = gamma rstd (dy - mean(dy) - xhat mean(dy xhat));  cxrk_bn_train_dz;
+ *              dz then takes the place of dy in cxrk_conv_bn_act_bwd_data* / _bwd_params* (identity fold).
+ */
+int cxrk_bn_train_fwd_coeffs(const float* mean, const float* var, const float* gamma, const float* beta, float eps, long n, float momentum,
+                             float* scale, float* shift, float* rstd, float* rmean, float* rvar, int C, hipStream_t stream);
+int cxrk_bn_apply(const void* z, long zplane, const float* scale, const float* shift, const void* res, long rplane, void* y, long yplane,
+                  unsigned char* mask, long rows, int C, int relu, hipStream_t stream);
+size_t cxrk_coldot_ws_bytes(long rows, int C);
+int cxrk_coldot(const void* a, long aplane, const void* b, long bplane, long rows, int C, float* out, float* ws, size_t ws_bytes,
+                hipStream_t stream);
+int cxrk_bn_train_bwd_coeffs(const float* gamma, const float* mean, const float* rstd, const float* sumdy, const float* dot, long n, float* A,
+                             float* B, float* Cc, float* dgamma, float* dbeta, int accumulate, int C, hipStream_t stream);
+int cxrk_bn_train_dz(const void* dy, long dyplane, const void* z, long zplane, const float* A, const float* B, const float* Cc, void* dz,
+                     long dzplane, long rows, int C, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * CXR-BERT pieces (HF BertForMaskedLM under modelling_cxrbert.py:87-99; config configuration_cxrbert.py:11-22).
  * embed_ln:    y = LayerNorm(word[ids] + pos[t % L] + type[0])                    (BertEmbeddings)
  * residual_ln: y = LayerNorm(x + res)                                             (BertSelfOutput / BertOutput)

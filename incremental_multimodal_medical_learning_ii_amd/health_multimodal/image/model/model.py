@@ -98,8 +98,9 @@ class ImageModel(nn.Module):
             self.load_state_dict(state_dict)
 
     def train(self, mode: bool = True, my_freeze: bool = False) -> Any:
-        """Switch between training and evaluation modes (`model.py:131-139`).  The forward refuses to run while a BatchNorm
-        layer is in training mode (see `_run`): use `.eval()` or `my_freeze=True`, as every reference call site does."""
+        """Switch between training and evaluation modes (`model.py:131-139`).  In training mode the BatchNorm layers normalise with
+        batch statistics and update their running statistics (csrc/bn_train.hip); `.eval()` / `my_freeze=True` — what every
+        reference call site uses — run them on the running statistics folded into the filters (the fast path `bench.py` measures)."""
         super().train(mode=mode)
         if my_freeze:
             print("freezing resnet encoder and projector")
@@ -123,17 +124,27 @@ class ImageModel(nn.Module):
             self._hot = ([named[n] for n in IE.param_names(self._specs)], [bufs[n] for n in IE.buffer_names(self._specs)])
         return self._hot
 
-    def _check_mode(self) -> None:
-        """Train-mode BatchNorm (batch statistics + running-stat updates, what `self.train()` at the end of the reference's
-        constructor selects) is NOT implemented: this path normalises with the running statistics, the only mode the
-        reference ever runs the encoder in (chexpert-get-embedding.py:41-42).  Refuse instead of silently computing
-        eval-mode numbers for a model that says it is in training mode."""
+    def _bn_mode(self) -> Optional[float]:
+        """None when every BatchNorm layer is in eval mode (running statistics: the only mode the reference ever runs the encoder in,
+        chexpert-get-embedding.py:41-42); their common momentum when every one is in training mode (batch statistics + running-stat
+        updates: what `self.train()` at the end of the reference's constructor selects).  Mixed states and `momentum=None`
+        (cumulative averaging) are refused."""
         if self._bn is None:
             self._bn = [m for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
-        if any(m.training for m in self._bn):
-            raise NotImplementedError("ImageModel: BatchNorm layers are in training mode (batch statistics), which the HIP path "
-                                      "does not implement; call .eval() (or .train(my_freeze=True)) first -- gamma/beta and all "
-                                      "filters still receive gradients in eval mode")
+        flags = {m.training for m in self._bn}
+        if flags == {False}:
+            return None
+        if flags != {True}:
+            raise NotImplementedError("ImageModel: some BatchNorm layers are in training mode and some in eval mode; the HIP path runs "
+                                      "them all on batch statistics (.train()) or all on running statistics (.eval() / .train(my_freeze=True))")
+        moms = {m.momentum for m in self._bn}
+        if len(moms) != 1 or None in moms:
+            raise NotImplementedError(f"ImageModel: train-mode BatchNorm needs one float momentum for all layers, got {moms}")
+        return float(moms.pop())
+
+    def _require_eval(self, what: str) -> None:
+        if self._bn_mode() is not None:
+            raise NotImplementedError(f"ImageModel.{what} runs on the running statistics: call .eval() first")
 
     def _run(self, x: torch.Tensor, want_patch: bool):
         if not x.is_cuda:
@@ -143,13 +154,17 @@ class ImageModel(nn.Module):
             raise ValueError(f"expected fp32 images, got {x.dtype}")
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f"ImageModel expects [B,3,H,W] input (ExpandChannels, transforms.py:12-38), got {tuple(x.shape)}")
-        self._check_mode()
+        momentum = self._bn_mode()
         self.prepare_()
         params, bufs = self._tensors()
         hook = self.grad_ready_hook if torch.is_grad_enabled() else None
-        meta = (self._specs, self._blocks, len(params), want_patch, hook)
+        meta = (self._specs, self._blocks, len(params), want_patch, hook, momentum)
         with torch.set_grad_enabled(torch.is_grad_enabled() and not self.freeze_encoder):
             emb, patch = IE.ImageEncodeFn.apply(x, meta, *params, *bufs)
+        if momentum is not None:       # the kernels updated running_mean / running_var in place; the counter is host bookkeeping
+            with torch.no_grad():
+                for m in self._bn:
+                    m.num_batches_tracked += 1
         return emb, patch
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -161,7 +176,7 @@ class ImageModel(nn.Module):
     def project_patch_embeddings(self, patch_embeddings: torch.Tensor) -> torch.Tensor:
         """The projector alone (reference `modules.MLP`, modules.py:29-47): trunk patch embeddings [B,2048,h,w] ->
         projected patch embeddings [B,joint,h,w]."""
-        self._check_mode()
+        self._require_eval("project_patch_embeddings")
         params, bufs = self._tensors()
         return IE.project_patches(self._specs, params, bufs, patch_embeddings)
 
@@ -180,7 +195,7 @@ class ImageModel(nn.Module):
     @torch.no_grad()
     def forward_stages(self, x: torch.Tensor):
         """Diagnostic: [max-pooled stem, layer1..layer4] outputs (fp32 NCHW) from the kernels `forward` runs."""
-        self._check_mode()
+        self._require_eval("forward_stages")
         self.prepare_()
         params, bufs = self._tensors()
         return IE.forward_stages(self._specs, self._blocks, params, bufs, x)

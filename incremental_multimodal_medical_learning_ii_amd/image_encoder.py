@@ -4,14 +4,19 @@ kernels, exposed as one `torch.autograd.Function`.
 Reference arithmetic: `health_multimodal/image/model/resnet.py:34-47` (stem, max-pool, layer1..4),
 torchvision 0.10 `Bottleneck` (1x1 -> 3x3(stride) -> 1x1, BN after each, residual add, ReLU; 1x1-stride downsample
 + BN on the first block of a stage), `model.py:141-145` (trunk -> projector -> mean over (H, W)) and
-`modules.py:43-47` (projector).  BatchNorm uses its running statistics — the only mode the reference runs the
-encoder in (`chexpert-get-embedding.py:41-42`) — but gamma/beta (and every conv weight) still receive gradients:
+`modules.py:43-47` (projector).  Eval-mode BatchNorm (running statistics) is the only mode the reference runs the encoder in
+(`chexpert-get-embedding.py:41-42`) and the one everything below is organised around — gamma/beta (and every conv weight) still
+receive gradients:
 
     y = conv(x, w)*s + t,  s = gamma*rsqrt(var+eps),  t = beta - mean*s
     dx = conv^T(dy, w*s);  dw = s * wgrad(x, dy);  dbeta = sum(dy);  dgamma = rstd * (<w, wgrad(x, dy)> - mean*sum(dy))
 
 (dgamma = sum dy*xhat written through the raw weight gradient: nothing of the forward has to be re-read for it and gamma is
 never divided by; measured against the direct sum on this network: < 1e-6 of the tensor maximum, scripts/exp_dgamma.py.)
+
+Train-mode BatchNorm (`ImageModel.train()`, the state the reference's constructor leaves the model in, `model.py:119`) runs the same
+GEMM kernels with an identity fold: batch statistics, normalisation + ReLU, running-statistics update and the batch-statistics terms
+of the backward are separate kernels around them (`_conv_bn_train`, `through_bn` in `_backward`, csrc/bn_train.hip).
 
 Working layout: activations NHWC, filters [Ko][R][S][C] (the parameters are kept in torch `channels_last` memory
 format, so state-dict shapes stay OIHW).  The stem's 3 input channels are zero-padded to 4 (16-byte loads).
@@ -111,6 +116,8 @@ class _Fold:
             a += (n + 7) // 8 * 8
             b += s.cout
         self.sizes = sizes
+        self.train = False      # train-mode BatchNorm (batch statistics): filters folded with an identity BatchNorm, see `_conv_bn_train`
+        self.tstate = None      # train mode with gradients: {unit: (raw convolution output z, batch mean, batch rstd)} for the backward
         if pl:
             self.wp = torch.empty(2, a, dtype=torch.bfloat16, device=device)
             self.w = torch.empty(sizes[0], dtype=torch.float32, device=device)    # the stem's filters stay fp32
@@ -159,22 +166,60 @@ def _conv(i, s, fold, x, residual, relu, N, H, W, pl, want_mask=True):
     return y, mask
 
 
+def _conv_bn_train(i, s, fold, p, bufs, x, residual, relu, N, H, W, pl, want_mask, momentum):
+    """Unit i in TRAIN mode (`torch.nn.BatchNorm2d`, training=True): z = conv(x, w) by the GEMM kernel (identity fold), batch
+    statistics over all N*Ho*Wo pixels (two passes: mean, then squared deviations), y = relu(gamma (z - mean) rstd + beta +
+    residual), running statistics updated with `momentum` (unbiased variance).  -> (y, mask)"""
+    z, _ = _conv(i, s, fold, x, None, False, N, H, W, pl, want_mask=False)
+    C = s.cout
+    rows = z.numel() // C
+    z2 = z.view(rows, C)
+    dev = fold.vec.device
+    mean = K.colsum(z2, torch.empty(C, dtype=torch.float32, device=dev), alpha=1.0 / rows)
+    var = K.colvar(z2, mean, torch.empty(C, dtype=torch.float32, device=dev), alpha=1.0 / rows)          # biased, as the forward uses it
+    scale, shift, rstd = K.bn_train_fwd_coeffs(mean, var, p[3 * i + 1], p[3 * i + 2], BN_EPS, rows, momentum, bufs[2 * i], bufs[2 * i + 1])
+    y, mask = K.bn_apply(z, scale, shift, residual, relu, want_mask and pl)
+    if fold.tstate is not None:
+        fold.tstate[i] = (z, mean, rstd)
+    return y, mask
+
+
 def _forward(specs, blocks, p: Sequence[torch.Tensor], bufs: Sequence[torch.Tensor], x: torch.Tensor, save: bool,
-             want_patch: bool, stages: Optional[list] = None, keep_stem: bool = False):
+             want_patch: bool, stages: Optional[list] = None, keep_stem: bool = False, bn_momentum: Optional[float] = None):
+    """bn_momentum: None = eval-mode BatchNorm (running statistics folded into the filters, the reference's only use of the encoder);
+    a float = train-mode BatchNorm with that momentum (batch statistics; `ImageModel.train()`)."""
     N, C, H, W = x.shape
     if C != 3:
         raise ValueError(f"ImageModel expects 3-channel input (ExpandChannels, transforms.py:12-38), got {C}")
     dev = x.device
     pl = _planes_mode()
     fold = _Fold(specs, dev, pl)
+    train = bn_momentum is not None
+    fold.train = train
+    if train and save:
+        fold.tstate = {}
+    ident = {}
     for i, s in enumerate(specs):
-        args = (_filter_rsc(p[3 * i]), p[3 * i + 1], p[3 * i + 2], bufs[2 * i], bufs[2 * i + 1], BN_EPS, s.cout, s.k * s.k, s.cin, s.cpad)
+        if train:   # identity BatchNorm: the GEMM kernels then produce the raw convolution output (scale 1, shift 0)
+            if s.cout not in ident:
+                one, zero = torch.ones(s.cout, device=dev), torch.zeros(s.cout, device=dev)
+                ident[s.cout] = (one, zero, zero, one - BN_EPS)        # gamma, beta, mean, var: rsqrt(var + eps) = 1
+            bn = ident[s.cout]
+        else:
+            bn = (p[3 * i + 1], p[3 * i + 2], bufs[2 * i], bufs[2 * i + 1])
+        args = (_filter_rsc(p[3 * i]), *bn, BN_EPS, s.cout, s.k * s.k, s.cin, s.cpad)
         if pl and i > 0:
             K.bn_fold_pl(*args, fold.ws(i, s), fold.scale(i, s), fold.shift(i, s), fold.rstd(i, s))
         else:
             K.bn_fold(*args, fold.ws(i, s), fold.scale(i, s), fold.shift(i, s), fold.rstd(i, s))
+
+    def unit(i, s, fold, x, residual, relu, N, H, W, pl, want_mask=True):   # conv + BatchNorm (+ residual, ReLU) of unit i in the mode of this pass
+        if train:
+            return _conv_bn_train(i, s, fold, p, bufs, x, residual, relu, N, H, W, pl, want_mask, bn_momentum)
+        return _conv(i, s, fold, x, residual, relu, N, H, W, pl, want_mask)
+
     x0 = K.nchw_to_nhwc(x, 4)
-    stem, _ = _conv(0, specs[0], fold, x0, None, True, N, H, W, pl, want_mask=False)   # its ReLU mask = sign of the pooled value
+    stem, _ = unit(0, specs[0], fold, x0, None, True, N, H, W, pl, want_mask=False)   # its ReLU mask = sign of the pooled value
     Hs, Ws = stem.shape[1], stem.shape[2]
     pooled, idx = K.maxpool_fwd_pl(stem) if pl else K.maxpool_fwd(stem)
     if pl and not keep_stem:
@@ -186,14 +231,14 @@ def _forward(specs, blocks, p: Sequence[torch.Tensor], bufs: Sequence[torch.Tens
     binfo = []
     for bi, blk in enumerate(blocks):
         s1, s2, s3 = specs[blk["c1"]], specs[blk["c2"]], specs[blk["c3"]]
-        o1, m1 = _conv(blk["c1"], s1, fold, cur, None, True, N, h, w, pl)
-        o2, m2 = _conv(blk["c2"], s2, fold, o1, None, True, N, h, w, pl)
+        o1, m1 = unit(blk["c1"], s1, fold, cur, None, True, N, h, w, pl)
+        o2, m2 = unit(blk["c2"], s2, fold, o1, None, True, N, h, w, pl)
         h2, w2 = o2.shape[1], o2.shape[2]
         if blk["ds"] is not None:
-            idt, _ = _conv(blk["ds"], specs[blk["ds"]], fold, cur, None, False, N, h, w, pl)
+            idt, _ = unit(blk["ds"], specs[blk["ds"]], fold, cur, None, False, N, h, w, pl)
         else:
             idt = cur
-        out, m3 = _conv(blk["c3"], s3, fold, o2, idt, True, N, h2, w2, pl)
+        out, m3 = unit(blk["c3"], s3, fold, o2, idt, True, N, h2, w2, pl)
         if save:
             # fp32 mode keeps `out` for its sign; planes mode keeps the three bit masks instead (out lives on as the next `cur`)
             binfo.append((cur, o1, o2, out if not pl else None, h, w, h2, w2, m1, m2, m3))
@@ -201,7 +246,7 @@ def _forward(specs, blocks, p: Sequence[torch.Tensor], bufs: Sequence[torch.Tens
         if stages is not None and (bi + 1 == len(blocks) or blocks[bi + 1]["ds"] is not None):
             stages.append(cur)
     ip = len(specs) - 1
-    pj1, mp = _conv(ip, specs[ip], fold, cur, None, True, N, h, w, pl)
+    pj1, mp = unit(ip, specs[ip], fold, cur, None, True, N, h, w, pl)
     w3, b3 = p[3 * len(specs)], p[3 * len(specs) + 1]
     w3m = w3.reshape(w3.shape[0], -1)
     if pl:
@@ -220,10 +265,16 @@ def _unit_params_bwd(i, s, fold, p, bufs, x, dy, sumdy, N, H, W, sink: GradSink,
     """Parameter gradients of conv+BN unit i.  x: its input; dy: masked gradient w.r.t. its BN output; sumdy = sum of dy over
     pixels ([cout], reduced by the kernel that produced dy)."""
     w = _filter_rsc(p[3 * i])
-    trip = [sink.dst(3 * i + k) for k in range(3)]
-    if len({acc for _, acc in trip}) > 1:          # one accumulate switch per launch: all three direct, or all three fresh
-        trip = [sink.dst(3 * i + k, force_fresh=True) for k in range(3)]
-    (gw, acc), (dg, _), (db, _) = trip
+    if fold.train:   # train-mode BatchNorm: dy is dz (gradient w.r.t. the raw convolution output), gamma / beta gradients are already
+        #              written by `through_bn`; the kernel's own gamma / beta outputs go to scratch
+        gw, acc = sink.dst(3 * i)
+        dg = torch.empty(s.cout, dtype=torch.float32, device=w.device)
+        db = torch.empty(s.cout, dtype=torch.float32, device=w.device)
+    else:
+        trip = [sink.dst(3 * i + k) for k in range(3)]
+        if len({acc for _, acc in trip}) > 1:          # one accumulate switch per launch: all three direct, or all three fresh
+            trip = [sink.dst(3 * i + k, force_fresh=True) for k in range(3)]
+        (gw, acc), (dg, _), (db, _) = trip
     if not acc and not gw.permute(0, 2, 3, 1).is_contiguous():     # fresh tensor: give it the filter's [Ko][R][S][C] memory
         gw = torch.empty_like(w).permute(0, 3, 1, 2)
         sink.ret[3 * i] = gw
@@ -277,6 +328,24 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
         if on_grads_ready is not None:
             on_grads_ready(stage)
 
+    tstate = fold.tstate
+
+    def through_bn(i, s_, dy_, sum_):
+        """TRAIN-mode BatchNorm of unit i: the gradient w.r.t. its output (already masked by the unit's ReLU) and its column sums ->
+        the gradient w.r.t. the raw convolution output, dz = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)); writes dgamma = sum dy
+        xhat and dbeta = sum dy.  Eval mode: the identity (the running statistics are constants folded into the filters)."""
+        if tstate is None:
+            return dy_, sum_
+        z, mean, rstd = tstate.pop(i)
+        C = s_.cout
+        rows = z.numel() // C
+        (dg, a1), (db, a2) = sink.dst(3 * i + 1), sink.dst(3 * i + 2)
+        if a1 != a2:
+            (dg, a1), (db, a2) = sink.dst(3 * i + 1, True), sink.dst(3 * i + 2, True)
+        dot = K.coldot(dy_, z)
+        A, B, Cc = K.bn_train_bwd_coeffs(p[3 * i + 1], mean, rstd, sum_, dot, rows, dg, db, a1)
+        return K.bn_train_dz(dy_, z, A, B, Cc), torch.zeros(C, dtype=torch.float32, device=dev)   # sum of dz over the pixels is 0
+
     ns = len(specs)
     ip = ns - 1
     w3 = p[3 * ns]
@@ -313,6 +382,7 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
         g = K.linear_bwd_data(dpj2, w3m, aux=pj1m, auxmode=K.AUX_RELU_MASK)
         sum_p = K.colsum(g, torch.empty(g.shape[1], dtype=torch.float32, device=dev))
         g = g.view(N, h, w, -1)
+    g, sum_p = through_bn(ip, specs[ip], g, sum_p)
     params_bwd(ip, specs[ip], last, g, sum_p, N, h, w, pl)
 
     nb = len(blocks)
@@ -328,16 +398,22 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
         s1, s2, s3 = specs[blk["c1"]], specs[blk["c2"]], specs[blk["c3"]]
         # out = relu(bn3(conv3(o2)) + identity): g (already masked by out > 0) is dy of bn3 and of the downsample BN; its
         # channel sums gs were reduced by the kernel that produced g
-        params_bwd(blk["c3"], s3, o2, g, gs, N, h2, w2, pl)
-        d2, q2 = _dgrad(blk["c3"], s3, fold, g, None, m2 if pl else o2, N, h2, w2, pl, True)
+        g3, gs3 = through_bn(blk["c3"], s3, g, gs)       # (eval mode: g itself; the downsample BatchNorm below sees the same g)
+        params_bwd(blk["c3"], s3, o2, g3, gs3, N, h2, w2, pl)
+        d2, q2 = _dgrad(blk["c3"], s3, fold, g3, None, m2 if pl else o2, N, h2, w2, pl, True)
+        del g3
+        d2, q2 = through_bn(blk["c2"], s2, d2, q2)
         params_bwd(blk["c2"], s2, o1, d2, q2, N, hi, wi, pl)
         d1, q1 = _dgrad(blk["c2"], s2, fold, d2, None, m1 if pl else o1, N, hi, wi, pl, True)
         del d2
+        d1, q1 = through_bn(blk["c1"], s1, d1, q1)
         params_bwd(blk["c1"], s1, cur, d1, q1, N, hi, wi, pl)
         if blk["ds"] is not None:
             sd = specs[blk["ds"]]
-            params_bwd(blk["ds"], sd, cur, g, gs, N, hi, wi, pl)
-            res = _dgrad(blk["ds"], sd, fold, g, None, None, N, hi, wi, pl, False)
+            gd, gsd = through_bn(blk["ds"], sd, g, gs)
+            params_bwd(blk["ds"], sd, cur, gd, gsd, N, hi, wi, pl)
+            res = _dgrad(blk["ds"], sd, fold, gd, None, None, N, hi, wi, pl, False)
+            del gd
         else:
             res = g
         if bi > 0:
@@ -358,6 +434,7 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
     if _debug is not None:
         _debug["ds"], _debug["x0"] = ds, x0
     sum_s = K.colsum(ds.view(-1, ds.shape[-1]), torch.empty(ds.shape[-1], dtype=torch.float32, device=dev))
+    ds, sum_s = through_bn(0, specs[0], ds, sum_s)
     params_bwd(0, specs[0], x0, ds, sum_s, N, H, W, False)   # fp32 operands (the image), split on the fly in split_bf16 mode
     if on_grads_ready is not None and all(r is None for r in sink.ret):
         report("stem")
@@ -542,7 +619,8 @@ class ImageEncodeFn(torch.autograd.Function):
         save = any(t.requires_grad for t in params)
         p = [t.detach() for t in params]
         b = [t.detach() for t in bufs]
-        emb, patch, state = _forward(specs, blocks, p, b, x.detach(), save, want_patch, keep_stem=_capture is not None)
+        momentum = meta[5] if len(meta) > 5 else None     # None: eval-mode BatchNorm; float: train mode (ImageModel.train())
+        emb, patch, state = _forward(specs, blocks, p, b, x.detach(), save, want_patch, keep_stem=_capture is not None, bn_momentum=momentum)
         if save:
             ctx.state, ctx.p, ctx.b, ctx.meta, ctx.params = state, p, b, meta, params
             if _capture is not None:

@@ -440,6 +440,106 @@ def colvar(x, mean: torch.Tensor, out: torch.Tensor, alpha: float = 1.0) -> torc
     return out
 
 
+# ---- train-mode BatchNorm2d around the convolutions (csrc/bn_train.hip) ------------------------------------------------------------
+
+def _fmt(t, name: str):
+    """(pointer, plane stride) of a contiguous fp32 tensor (plane 0) or Planes tensor"""
+    if isinstance(t, Planes):
+        if not t.is_contiguous():
+            raise ValueError(f"{name}: planes tensor must be contiguous")
+        return t.ptr(), t.plane
+    _chk(t, name)
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t.data_ptr(), 0
+
+
+def _vec(t: torch.Tensor, C: int, name: str) -> torch.Tensor:
+    _chk(t, name)
+    if t.numel() != C or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous vector of {C} elements, got {tuple(t.shape)}")
+    return t
+
+
+def bn_train_fwd_coeffs(mean, var, gamma, beta, eps: float, n: int, momentum: float = 0.0, rmean=None, rvar=None):
+    """(scale, shift, rstd) of a train-mode BatchNorm from its batch statistics (var: biased); updates the running statistics in place
+    (r = (1 - momentum) r + momentum stat, unbiased variance) when given."""
+    lib = _lib.load()
+    C = mean.numel()
+    for nme, t in (("mean", mean), ("var", var), ("gamma", gamma), ("beta", beta)):
+        _vec(t, C, "bn_train." + nme)
+    scale, shift, rstd = (torch.empty(C, dtype=torch.float32, device=mean.device) for _ in range(3))
+    if rmean is not None:
+        _vec(rmean, C, "bn_train.running_mean")
+        _vec(rvar, C, "bn_train.running_var")
+    check(lib.cxrk_bn_train_fwd_coeffs(_p(mean), _p(var), _p(gamma), _p(beta), float(eps), int(n), float(momentum), _p(scale), _p(shift),
+                                       _p(rstd), _p(rmean), _p(rvar), C, _stream()), "cxrk_bn_train_fwd_coeffs")
+    return scale, shift, rstd
+
+
+def bn_apply(z, scale, shift, residual=None, relu: bool = True, want_mask: bool = False):
+    """y = relu?(z * scale + shift + residual?) in z's storage format ([..., C], C % 8 == 0); mask: ReLU decision bits [rows, C / 8]."""
+    lib = _lib.load()
+    C = z.shape[-1]
+    rows = z.numel() // C
+    zp, zpl = _fmt(z, "bn_apply.z")
+    if isinstance(z, Planes):
+        y = Planes.empty(*z.shape, device=z.device)
+    else:
+        y = torch.empty_like(z)
+    yp, ypl = _fmt(y, "bn_apply.y")
+    rp, rpl = _fmt(residual, "bn_apply.residual") if residual is not None else (None, 0)
+    if residual is not None and tuple(residual.shape) != tuple(z.shape):
+        raise ValueError(f"bn_apply: residual {tuple(residual.shape)} vs z {tuple(z.shape)}")
+    mask = torch.empty(rows, C // 8, dtype=torch.uint8, device=z.device) if (want_mask and relu) else None
+    check(lib.cxrk_bn_apply(zp, zpl, _p(_vec(scale, C, "bn_apply.scale")), _p(_vec(shift, C, "bn_apply.shift")), rp, rpl, yp, ypl, _p(mask),
+                            rows, C, int(relu), _stream()), f"cxrk_bn_apply(rows={rows},C={C})")
+    return y, mask
+
+
+def coldot(a, b) -> torch.Tensor:
+    """out[c] = sum_rows a[r, c] * b[r, c]; a, b: [..., C] fp32 or Planes (formats may differ)."""
+    lib = _lib.load()
+    C = a.shape[-1]
+    rows = a.numel() // C
+    if b.shape[-1] != C or b.numel() != a.numel():
+        raise ValueError(f"coldot: {tuple(a.shape)} vs {tuple(b.shape)}")
+    ap, apl = _fmt(a, "coldot.a")
+    bp, bpl = _fmt(b, "coldot.b")
+    out = torch.empty(C, dtype=torch.float32, device=a.device)
+    ws = workspace(lib.cxrk_coldot_ws_bytes(rows, C), a.device)
+    check(lib.cxrk_coldot(ap, apl, bp, bpl, rows, C, _p(out), _p(ws), ws.numel() * 4, _stream()), "cxrk_coldot")
+    return out
+
+
+def bn_train_bwd_coeffs(gamma, mean, rstd, sumdy, dot, n: int, dgamma, dbeta, accumulate: bool):
+    """dgamma (+)= rstd (dot - mean sumdy), dbeta (+)= sumdy; returns (A, B, Cc) with dz = A dy + B + Cc z."""
+    lib = _lib.load()
+    C = gamma.numel()
+    for nme, t in (("gamma", gamma), ("mean", mean), ("rstd", rstd), ("sumdy", sumdy), ("dot", dot), ("dgamma", dgamma), ("dbeta", dbeta)):
+        _vec(t, C, "bn_train_bwd." + nme)
+    A, B, Cc = (torch.empty(C, dtype=torch.float32, device=gamma.device) for _ in range(3))
+    check(lib.cxrk_bn_train_bwd_coeffs(_p(gamma), _p(mean), _p(rstd), _p(sumdy), _p(dot), int(n), _p(A), _p(B), _p(Cc), _p(dgamma), _p(dbeta),
+                                       int(accumulate), C, _stream()), "cxrk_bn_train_bwd_coeffs")
+    return A, B, Cc
+
+
+def bn_train_dz(dy, z, A, B, Cc):
+    """dz = A dy + B + Cc z (per channel), in dy's storage format."""
+    lib = _lib.load()
+    C = dy.shape[-1]
+    rows = dy.numel() // C
+    dp, dpl = _fmt(dy, "bn_train_dz.dy")
+    zp, zpl = _fmt(z, "bn_train_dz.z")
+    if z.numel() != dy.numel():
+        raise ValueError(f"bn_train_dz: {tuple(dy.shape)} vs {tuple(z.shape)}")
+    dz = Planes.empty(*dy.shape, device=dy.device) if isinstance(dy, Planes) else torch.empty_like(dy)
+    op, opl = _fmt(dz, "bn_train_dz.dz")
+    check(lib.cxrk_bn_train_dz(dp, dpl, zp, zpl, _p(_vec(A, C, "A")), _p(_vec(B, C, "B")), _p(_vec(Cc, C, "Cc")), op, opl, rows, C, _stream()),
+          "cxrk_bn_train_dz")
+    return dz
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # image encoder pieces (NHWC)
 # ----------------------------------------------------------------------------------------------------------------

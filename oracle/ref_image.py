@@ -15,7 +15,7 @@ the encoder in (`chexpert-get-embedding.py:41-42`).
 """
 from __future__ import annotations
 
-from typing import Dict, List, Tuple
+from typing import Optional, Dict, List, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -82,7 +82,33 @@ class ReluPolicy:
 _PLAIN = ReluPolicy()
 
 
+# BatchNorm mode of the restatement: None = eval (running statistics, the reference's every use of the encoder); a float = train
+# mode with that momentum (`torch.nn.BatchNorm2d`, training=True: what `ImageModel.train()` selects, model.py:119,131-139).
+_BN_MOMENTUM: Optional[float] = None
+
+
+class bn_training:
+    """`with bn_training(0.1): ...` runs the restatement with train-mode BatchNorm: batch statistics in the forward (and their terms
+    in autograd's backward), running statistics in the parameter dict updated in place."""
+
+    def __init__(self, momentum: float = 0.1):
+        self.momentum = momentum
+
+    def __enter__(self):
+        global _BN_MOMENTUM
+        self._old, _BN_MOMENTUM = _BN_MOMENTUM, self.momentum
+        return self
+
+    def __exit__(self, *exc):
+        global _BN_MOMENTUM
+        _BN_MOMENTUM = self._old
+        return False
+
+
 def _bn(p: P, name: str, x: torch.Tensor, training: bool = False) -> torch.Tensor:
+    if _BN_MOMENTUM is not None:
+        return F.batch_norm(x, p[name + ".running_mean"], p[name + ".running_var"], p[name + ".weight"], p[name + ".bias"],
+                            training=True, momentum=_BN_MOMENTUM, eps=BN_EPS)
     return F.batch_norm(x, p[name + ".running_mean"], p[name + ".running_var"], p[name + ".weight"],
                         p[name + ".bias"], training=training, eps=BN_EPS)
 

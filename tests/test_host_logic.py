@@ -83,15 +83,26 @@ def test_models_fail_loudly_on_cpu():
         ImageModel("resnet18", 128)
 
 
-def test_training_mode_is_refused_not_silently_replaced_by_eval_semantics():
-    """The reference constructor leaves ImageModel in train mode (model.py:119): batch-statistic BatchNorm, which this path
-    does not implement -> it must raise, not run eval-mode arithmetic.  Same for dropout in CXRBertModel."""
+def test_training_mode_selects_batch_statistics_and_is_never_silently_eval():
+    """The reference constructor leaves ImageModel in train mode (model.py:119): batch-statistic BatchNorm.  The path's mode switch
+    follows the BatchNorm layers: all training -> their momentum (the train-mode kernels), all eval -> None (running statistics folded
+    into the filters); a mixed state or `momentum=None` is refused, never silently run as one of the two.  Dropout in CXRBertModel
+    is not implemented and is refused."""
     im = get_biovil_resnet(None)
-    assert im.training
-    with pytest.raises(NotImplementedError, match="training mode"):
-        im._check_mode()
-    im.eval()._check_mode()
-    im.train(my_freeze=True)._check_mode()                      # reference :131-139: encoder + projector frozen in eval
+    assert im.training and im._bn_mode() == 0.1                   # torch.nn.BatchNorm2d default momentum
+    assert im.eval()._bn_mode() is None
+    assert im.train(my_freeze=True)._bn_mode() is None            # reference :131-139: encoder + projector frozen in eval
+    im.train()
+    im.projector.model[1].eval()
+    with pytest.raises(NotImplementedError, match="some BatchNorm"):
+        im._bn_mode()
+    im.train()
+    im.encoder.encoder.bn1.momentum = None
+    with pytest.raises(NotImplementedError, match="momentum"):
+        im._bn_mode()
+    im.encoder.encoder.bn1.momentum = 0.1
+    with pytest.raises(NotImplementedError, match="running statistics"):
+        im.forward_stages(torch.zeros(1, 3, 32, 32))
     cfg = CXRBertConfig(vocab_size=64, hidden_size=32, num_attention_heads=2, intermediate_size=64, num_hidden_layers=1,
                         max_position_embeddings=16)
     tm = CXRBertModel(cfg).train()

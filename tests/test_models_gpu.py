@@ -206,6 +206,46 @@ def test_batchnorm_calibration_matches_a_train_mode_pass(monkeypatch):
     assert rel(emb, ref) < TOL
 
 
+def test_image_model_train_mode_batchnorm():
+    """`ImageModel.train()` — the state the reference's constructor leaves the model in (model.py:119): BatchNorm on BATCH statistics.
+    Forward, every parameter gradient (under the implementation's own ReLU / max-pool decisions, as in the eval-mode test), the
+    running statistics after the pass and `num_batches_tracked`, against the CPU oracle with `F.batch_norm(training=True,
+    momentum=0.1)`; then `.eval()` runs on the updated running statistics."""
+    from incremental_multimodal_medical_learning_ii_amd import image_encoder as IE
+    from oracle import ref_image
+    model = get_biovil_resnet(None)
+    syn.fill_module_(model)
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).train()
+    x = syn.synthetic_images(4, 96, seed=13)
+    probe = torch.randn(4, 128, generator=torch.Generator().manual_seed(14))
+    with IE.capture_relu_decisions() as cap:
+        emb = model(x.to(DEV))
+    (emb * probe.to(DEV)).sum().backward()
+    named = dict(model.named_parameters())
+    with ref_image.bn_training(0.1):
+        emb_ref, gref, pol = _image_oracle_with_decisions(sd_cpu, x, probe, cap[0])
+    split = _cxr_lib.get_precision() == "split_bf16"
+    assert rel(emb, emb_ref) < TOL, rel(emb, emb_ref)
+    assert pol.flips <= (20000 if split else 50) and pol.max_flip_rel < (5e-3 if split else 1e-4), (pol.flips, pol.max_flip_rel)
+    worst = max(((rel(named[k].grad, v), k) for k, v in gref.items()), key=lambda t: t[0])
+    assert worst[0] < (3e-3 if split else TOL), worst        # batch statistics over as few as 36 pixels amplify the split-bf16 rounding
+    # running statistics: (1 - 0.1) * old + 0.1 * batch (unbiased variance); the oracle updates its parameter dict in place
+    p2 = {k: v.clone() for k, v in sd_cpu.items()}
+    with ref_image.bn_training(0.1), torch.no_grad():
+        ref_image.image_model_forward(p2, x)
+    msd = model.state_dict()
+    for k, v in p2.items():
+        if "running_" in k and ".fc." not in k:
+            assert rel(msd[k], v) < (2e-3 if split else 1e-4), (k, rel(msd[k], v))
+    assert int(msd["encoder.encoder.layer2.1.bn2.num_batches_tracked"]) == 1 and int(msd["projector.model.1.num_batches_tracked"]) == 1
+    model.eval()
+    with torch.no_grad():
+        e_eval = model(x.to(DEV))
+    ref_eval = ref_image.image_model_forward({k: v.detach().cpu() for k, v in model.state_dict().items()}, x)
+    assert rel(e_eval, ref_eval) < TOL and rel(e_eval, emb_ref) > 1e-2      # a different function than the train-mode pass
+
+
 def test_reference_pinned_image_fixtures_through_the_hip_path(golden_dir):
     """The vectors of g3_image.npz that were produced by the reference's OWN code (modules.MLP on `proj_patch_in`) and the
     oracle's trunk checksums go through the HIP kernels directly, not only through the oracle."""

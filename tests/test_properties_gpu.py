@@ -213,6 +213,18 @@ def test_joint_step_overfits_a_small_batch():
     trace = [float(tr.step(images, ids.to(DEV), mask.to(DEV))) for _ in range(40)]
     assert trace[0] > math.log(B) and all(math.isfinite(x) for x in trace), trace[:3]
     assert trace[-1] < 0.1 and min(trace[-5:]) < 0.05 * trace[0], (trace[0], trace[-5:])
+    # the same with the image encoder's BatchNorm in TRAIN mode (batch statistics, the reference constructor's default state): no
+    # calibration needed, the normalisation follows the batch
+    im2 = get_biovil_resnet(None)
+    tm2 = CXRBertModel(CXRBertConfig(vocab_size=2048, hidden_size=128, num_attention_heads=2, intermediate_size=256, num_hidden_layers=2,
+                                     max_position_embeddings=32)).eval()
+    syn.fill_module_(im2)
+    syn.fill_module_(tm2)
+    tr2 = JointContrastiveTrainer(im2.to(DEV).train(), tm2.to(DEV), lr=1e-4, temperature=0.07)
+    before = im2.encoder.encoder.layer3[0].bn1.running_mean.clone()
+    trace2 = [float(tr2.step(images, ids.to(DEV), mask.to(DEV))) for _ in range(40)]
+    assert all(math.isfinite(x) for x in trace2) and trace2[-1] < 0.1 and min(trace2[-5:]) < 0.05 * trace2[0], (trace2[0], trace2[-5:])
+    assert int(im2.projector.model[1].num_batches_tracked) == 40 and not torch.equal(im2.encoder.encoder.layer3[0].bn1.running_mean, before)
 
 
 def test_embedding_precompute_at_reference_image_size():
