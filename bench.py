@@ -87,6 +87,9 @@ def parse():
     ap.add_argument("--temperature", type=float, default=0.07)
     ap.add_argument("--lr", type=float, default=LR_DEFAULT, help="Adam learning rate of the timed steps")
     ap.add_argument("--no-bn-calibration", action="store_true", help="keep the name-keyed BatchNorm statistics of synthetic.fill_module_")
+    ap.add_argument("--batchnorm", default="eval", choices=["eval", "train"],
+                    help="image-encoder BatchNorm mode of the timed steps: eval = running statistics folded into the filters (the only mode "
+                         "the reference runs the encoder in; the headline), train = batch statistics (a labelled variant)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=64)
     ap.add_argument("--cpu-baseline-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -334,6 +337,9 @@ def main():
         # step at any usable learning rate then pins the loss at ln(B) with zero cotangents (round 2's bench).  One calibration
         # pass over a fixed sample (same on every rank) gives the synthetic weights that property; it is set-up, not timed.
         im.calibrate_batchnorm_(structured_images(64, args.image_size, seed=4242).to(dev))
+    if args.batchnorm == "train":
+        im.train()
+        args.no_secondary = True              # the precision / secondary legs are defined for the eval-mode headline only
     trainer = JointContrastiveTrainer(im, tm.to(dev), lr=args.lr, temperature=args.temperature)
     B = args.batch_per_gpu
     NB = 4                                      # resident batches the steps rotate through
@@ -530,7 +536,8 @@ def main():
                                   "; BatchNorm running statistics calibrated on a 64-image sample (ImageModel.calibrate_batchnorm_)"),
                        "optimizer": f"Adam, lr {args.lr:g}",
                        "batches": f"{NB} resident synthetic batches, rotated",
-                       "batchnorm": "running statistics (eval mode), gamma/beta trained",
+                       "batchnorm": "running statistics (eval mode), gamma/beta trained" if args.batchnorm == "eval" else
+                                    "VARIANT: batch statistics (train mode, csrc/bn_train.hip), running statistics updated",
                        "precision": args.precision,
                        "precision_note": "split_bf16: activations / gradients / weights that feed a contraction are stored as bf16 hi+lo "
                                          "planes (4 B per element) and every product is hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 "

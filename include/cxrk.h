@@ -152,21 +152,26 @@ int cxrk_spatial_mean_bwd_pl(const float* dy, const float* add, void* dx, long d
  * model in (`self.train()`, health_multimodal/image/model/model.py:119) — batch statistics in the forward, running statistics updated
  * with momentum, the batch-statistics terms in the backward (torch.nn.BatchNorm2d, training=True).  Tensors `void* p, long plane`:
  * fp32 when plane == 0, split-bf16 planes otherwise; [rows = pixels][C], C % 8 == 0.
- *   forward:   z = conv(x, w) (cxrk_conv_bn_act_fwd* with an identity fold); mean = colsum(z) / n; var = colvar(z, mean) / n;
+ *   forward:   z = conv(x, w) (cxrk_conv_bn_act_fwd* with an identity fold); cxrk_colstats -> batch mean and biased variance;
  *              cxrk_bn_train_fwd_coeffs -> scale = gamma rstd, shift = beta - mean scale, rstd (+ running statistics update when
  *              rmean / rvar are given: r = (1 - momentum) r + momentum stat, variance unbiased);  cxrk_bn_apply: y = relu?(z scale +
  *              shift + residual?), ReLU decision bits (byte [row][c / 8]) when mask != null.
- *   backward:  dot = cxrk_coldot(dy, z) = sum_rows dy z;  cxrk_bn_train_bwd_coeffs -> dbeta (+)= sum dy, dgamma (+)= rstd (dot - mean
- *              sum dy), and A, B, Cc with dz = A dy + B + Cc z = gamma rstd (dy - mean(dy) - xhat mean(dy xhat));  cxrk_bn_train_dz;
+ *   backward:  dot = cxrk_coldot(dy, z, bshift = mean) = sum_rows dy (z - mean);  cxrk_bn_train_bwd_coeffs -> dbeta (+)= sum dy,
+ *              dgamma (+)= rstd dot, and A, B, Cc with dz = A dy + B + Cc z = gamma rstd (dy - mean(dy) - xhat mean(dy xhat));  cxrk_bn_train_dz;
  *              dz then takes the place of dy in cxrk_conv_bn_act_bwd_data* / _bwd_params* (identity fold).
  */
+/* mean[c], var[c] = var_scale * sum_rows (x - mean)^2 in ONE pass over x (per-block shifted sums merged with Chan's formula);
+ * ws: 2 * cxrk_coldot_ws_bytes(rows, C) */
+int cxrk_colstats(const void* x, long plane, long rows, int C, float* mean, float* var, float var_scale, float* ws, size_t ws_bytes,
+                  hipStream_t stream);
 int cxrk_bn_train_fwd_coeffs(const float* mean, const float* var, const float* gamma, const float* beta, float eps, long n, float momentum,
                              float* scale, float* shift, float* rstd, float* rmean, float* rvar, int C, hipStream_t stream);
 int cxrk_bn_apply(const void* z, long zplane, const float* scale, const float* shift, const void* res, long rplane, void* y, long yplane,
                   unsigned char* mask, long rows, int C, int relu, hipStream_t stream);
 size_t cxrk_coldot_ws_bytes(long rows, int C);
-int cxrk_coldot(const void* a, long aplane, const void* b, long bplane, long rows, int C, float* out, float* ws, size_t ws_bytes,
-                hipStream_t stream);
+/* out[c] = sum_rows a[r][c] * (b[r][c] - bshift[c]); bshift may be null (= 0) */
+int cxrk_coldot(const void* a, long aplane, const void* b, long bplane, const float* bshift, long rows, int C, float* out, float* ws,
+                size_t ws_bytes, hipStream_t stream);
 int cxrk_bn_train_bwd_coeffs(const float* gamma, const float* mean, const float* rstd, const float* sumdy, const float* dot, long n, float* A,
                              float* B, float* Cc, float* dgamma, float* dbeta, int accumulate, int C, hipStream_t stream);
 int cxrk_bn_train_dz(const void* dy, long dyplane, const void* z, long zplane, const float* A, const float* B, const float* Cc, void* dz,

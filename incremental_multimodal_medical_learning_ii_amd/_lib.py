@@ -37,10 +37,11 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_conv_wgrad_ws_bytes": (Z, [I, I, I, I, I, I, I, I, I]),
     "cxrk_conv_bn_act_bwd_params": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, Z, P]),
     "cxrk_conv_bn_act_bwd_params_pl": (I, [P, L, P, L, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, Z, P]),
+    "cxrk_colstats": (I, [P, L, L, I, P, P, F, P, Z, P]),
     "cxrk_bn_train_fwd_coeffs": (I, [P, P, P, P, F, L, F, P, P, P, P, P, I, P]),
     "cxrk_bn_apply": (I, [P, L, P, P, P, L, P, L, P, L, I, I, P]),
     "cxrk_coldot_ws_bytes": (Z, [L, I]),
-    "cxrk_coldot": (I, [P, L, P, L, L, I, P, P, Z, P]),
+    "cxrk_coldot": (I, [P, L, P, L, P, L, I, P, P, Z, P]),
     "cxrk_bn_train_bwd_coeffs": (I, [P, P, P, P, P, L, P, P, P, P, P, I, I, P]),
     "cxrk_bn_train_dz": (I, [P, L, P, L, P, P, P, P, L, L, I, P]),
     "cxrk_nchw_to_nhwc": (I, [P, P, I, I, I, I, I, P]),

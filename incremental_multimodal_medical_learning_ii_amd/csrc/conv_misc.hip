@@ -164,42 +164,74 @@ __global__ void maxpool_fwd_pl_kernel(const unsigned short* __restrict__ x, long
 }
 // dx (fp32: it feeds the stem's exact-fp32 weight gradient) = sum over the <= 4 windows whose winning tap is this pixel, masked
 // by the stem ReLU.  The pooled value IS the winning input, so (pooled > 0) is that input's ReLU decision: no second tensor.
-__global__ void maxpool_bwd_pl_kernel(const unsigned short* __restrict__ dy, long dyplane, const unsigned char* __restrict__ idx,
-                                      const unsigned short* __restrict__ pooled, float* __restrict__ dx, int N, int H, int W,
-                                      int C, int Ho, int Wo) {
+// A thread owns the 2 x 2 input pixels (2a + i, 2b + j) of 8 channels: they lie in the four windows (a | a + 1, b | b + 1) only
+// (3 x 3, stride 2, pad 1), which are loaded once (a thread per pixel loaded 9 windows for the same four pixels); each pixel's
+// sum runs over its windows in ascending tap order (r, s), as the per-pixel form did.
+struct PoolWin { float d[8]; unsigned tap[8]; };   // gradient (0 where the stem ReLU was off) and winning tap per channel
+__device__ __forceinline__ void pool_win_load(PoolWin& w, bool valid, const unsigned short* __restrict__ dy, long dyplane,
+                                              const unsigned char* __restrict__ idx, const unsigned short* __restrict__ pooled, long o) {
+  if (!valid) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { w.d[q] = 0.f; w.tap[q] = 0xffu; }
+    return;
+  }
+  const uint2 bw = *reinterpret_cast<const uint2*>(idx + o);
+  const uint4 ph = *reinterpret_cast<const uint4*>(pooled + o);   // hi plane: sign(hi) = sign(value)
+  planes_load8(dy, dyplane, o, w.d);
+  const unsigned pw[4] = {ph.x, ph.y, ph.z, ph.w};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    w.tap[q] = ((q < 4 ? bw.x : bw.y) >> (8 * (q & 3))) & 0xffu;
+    const float pv = __builtin_bit_cast(float, (q & 1) ? (pw[q >> 1] & 0xffff0000u) : (pw[q >> 1] << 16));
+    if (!(pv > 0.f)) w.tap[q] = 0xffu;
+  }
+}
+__device__ __forceinline__ void pool_acc(float (&g)[8], const PoolWin& w, unsigned tap) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) if (w.tap[q] == tap) g[q] += w.d[q];
+}
+__device__ __forceinline__ void pool_store(float* __restrict__ dx, long e, const float (&g)[8]) {
+  *reinterpret_cast<float4*>(dx + e) = make_float4(g[0], g[1], g[2], g[3]);
+  *reinterpret_cast<float4*>(dx + e + 4) = make_float4(g[4], g[5], g[6], g[7]);
+}
+__global__ __launch_bounds__(256) void maxpool_bwd_pl_kernel(const unsigned short* __restrict__ dy, long dyplane, const unsigned char* __restrict__ idx,
+                                                             const unsigned short* __restrict__ pooled, float* __restrict__ dx, int N, int H,
+                                                             int W, int C, int Ho, int Wo) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int C8 = C / 8;
-  const long total = (long)N * H * W * C8;
+  const int C8 = C / 8, H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const long total = (long)N * H2 * W2 * C8;
   if (t >= total) return;
   const int c8 = (int)(t % C8); long p = t / C8;
-  const int wi = (int)(p % W); p /= W; const int hi = (int)(p % H); const long n = p / H;
-  float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int r = 0; r < 3; ++r) {
-    const int hn = hi + 1 - r;
-    if (hn < 0 || (hn & 1)) continue;
-    const int ho = hn >> 1;
-    if (ho >= Ho) continue;
-    for (int s = 0; s < 3; ++s) {
-      const int wn = wi + 1 - s;
-      if (wn < 0 || (wn & 1)) continue;
-      const int wo = wn >> 1;
-      if (wo >= Wo) continue;
-      const long o = (((n * Ho + ho) * Wo + wo) * C8 + c8) * 8;
-      const uint2 bw = *reinterpret_cast<const uint2*>(idx + o);
-      const uint4 ph = *reinterpret_cast<const uint4*>(pooled + o);   // hi plane: sign(hi) = sign(value)
-      float d[8]; planes_load8(dy, dyplane, o, d);
-      const unsigned tap = (unsigned)(r * 3 + s);
-      const unsigned pw[4] = {ph.x, ph.y, ph.z, ph.w};
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const unsigned b = ((q < 4 ? bw.x : bw.y) >> (8 * (q & 3))) & 0xffu;
-        const float pv = __builtin_bit_cast(float, (q & 1) ? (pw[q >> 1] & 0xffff0000u) : (pw[q >> 1] << 16));
-        if (b == tap && pv > 0.f) g[q] += d[q];
-      }
-    }
+  const int b = (int)(p % W2); p /= W2; const int a = (int)(p % H2); const long n = p / H2;
+  PoolWin w00, w01, w10, w11;     // windows (a, b), (a, b + 1), (a + 1, b), (a + 1, b + 1)
+  const bool va = a < Ho, va1 = a + 1 < Ho, vb = b < Wo, vb1 = b + 1 < Wo;
+  const long o00 = (((n * Ho + a) * Wo + b) * C8 + c8) * 8;
+  pool_win_load(w00, va && vb, dy, dyplane, idx, pooled, o00);
+  pool_win_load(w01, va && vb1, dy, dyplane, idx, pooled, o00 + (long)C);
+  pool_win_load(w10, va1 && vb, dy, dyplane, idx, pooled, o00 + (long)Wo * C);
+  pool_win_load(w11, va1 && vb1, dy, dyplane, idx, pooled, o00 + (long)(Wo + 1) * C);
+  const int hi = 2 * a, wi = 2 * b;
+  const long e = (((n * H + hi) * W + wi) * C8 + c8) * 8;
+  {  // (even row, even column): tap (1,1) of window (a, b)
+    float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    pool_acc(g, w00, 4u);
+    pool_store(dx, e, g);
   }
-  *reinterpret_cast<float4*>(dx + t * 8) = make_float4(g[0], g[1], g[2], g[3]);
-  *reinterpret_cast<float4*>(dx + t * 8 + 4) = make_float4(g[4], g[5], g[6], g[7]);
+  if (wi + 1 < W) {  // (even, odd): tap (1,0) of (a, b + 1), then tap (1,2) of (a, b)
+    float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    pool_acc(g, w01, 3u); pool_acc(g, w00, 5u);
+    pool_store(dx, e + C, g);
+  }
+  if (hi + 1 < H) {  // (odd, even): tap (0,1) of (a + 1, b), then tap (2,1) of (a, b)
+    float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    pool_acc(g, w10, 1u); pool_acc(g, w00, 7u);
+    pool_store(dx, e + (long)W * C, g);
+  }
+  if (hi + 1 < H && wi + 1 < W) {  // (odd, odd): taps (0,0) of (a+1, b+1), (0,2) of (a+1, b), (2,0) of (a, b+1), (2,2) of (a, b)
+    float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    pool_acc(g, w11, 0u); pool_acc(g, w10, 2u); pool_acc(g, w01, 6u); pool_acc(g, w00, 8u);
+    pool_store(dx, e + (long)(W + 1) * C, g);
+  }
 }
 __global__ void spatial_mean_bwd_pl_kernel(const float* __restrict__ dy, const float* __restrict__ add, unsigned short* __restrict__ dx,
                                            long dxplane, int P, int C) {
@@ -289,7 +321,7 @@ extern "C" int cxrk_maxpool_bwd_pl(const void* dy, long dyplane, const unsigned 
                                    int W, int C, hipStream_t stream) {
   CXRK_CHECK_ARG(dy && idx && pooled && dx && C % 8 == 0 && aligned16(dy) && aligned16(pooled) && aligned16(dx) && (dyplane % 8) == 0);
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const long total = (long)N * H * W * (C / 8);
+  const long total = (long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);   // one thread per 2 x 2 input pixels x 8 channels
   hipLaunchKernelGGL(maxpool_bwd_pl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, static_cast<const unsigned short*>(dy),
                      dyplane, idx, static_cast<const unsigned short*>(pooled), dx, N, H, W, C, Ho, Wo);
   CXRK_LAUNCH_CHECK();

@@ -168,15 +168,12 @@ def _conv(i, s, fold, x, residual, relu, N, H, W, pl, want_mask=True):
 
 def _conv_bn_train(i, s, fold, p, bufs, x, residual, relu, N, H, W, pl, want_mask, momentum):
     """Unit i in TRAIN mode (`torch.nn.BatchNorm2d`, training=True): z = conv(x, w) by the GEMM kernel (identity fold), batch
-    statistics over all N*Ho*Wo pixels (two passes: mean, then squared deviations), y = relu(gamma (z - mean) rstd + beta +
-    residual), running statistics updated with `momentum` (unbiased variance).  -> (y, mask)"""
+    statistics over all N*Ho*Wo pixels (one pass: per-block shifted sums merged with Chan's formula), y = relu(gamma (z - mean) rstd
+    + beta + residual), running statistics updated with `momentum` (unbiased variance).  -> (y, mask)"""
     z, _ = _conv(i, s, fold, x, None, False, N, H, W, pl, want_mask=False)
     C = s.cout
     rows = z.numel() // C
-    z2 = z.view(rows, C)
-    dev = fold.vec.device
-    mean = K.colsum(z2, torch.empty(C, dtype=torch.float32, device=dev), alpha=1.0 / rows)
-    var = K.colvar(z2, mean, torch.empty(C, dtype=torch.float32, device=dev), alpha=1.0 / rows)          # biased, as the forward uses it
+    mean, var = K.colstats(z)                                        # one pass; biased variance, as the forward uses it
     scale, shift, rstd = K.bn_train_fwd_coeffs(mean, var, p[3 * i + 1], p[3 * i + 2], BN_EPS, rows, momentum, bufs[2 * i], bufs[2 * i + 1])
     y, mask = K.bn_apply(z, scale, shift, residual, relu, want_mask and pl)
     if fold.tstate is not None:
@@ -342,7 +339,7 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
         (dg, a1), (db, a2) = sink.dst(3 * i + 1), sink.dst(3 * i + 2)
         if a1 != a2:
             (dg, a1), (db, a2) = sink.dst(3 * i + 1, True), sink.dst(3 * i + 2, True)
-        dot = K.coldot(dy_, z)
+        dot = K.coldot(dy_, z, mean)                                # sum dy (z - mean): centred before it is summed
         A, B, Cc = K.bn_train_bwd_coeffs(p[3 * i + 1], mean, rstd, sum_, dot, rows, dg, db, a1)
         return K.bn_train_dz(dy_, z, A, B, Cc), torch.zeros(C, dtype=torch.float32, device=dev)   # sum of dz over the pixels is 0
 

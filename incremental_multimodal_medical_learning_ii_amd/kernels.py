@@ -461,6 +461,20 @@ def _vec(t: torch.Tensor, C: int, name: str) -> torch.Tensor:
     return t
 
 
+def colstats(x, unbiased: bool = False):
+    """(mean[C], var[C]) over the rows of x ([..., C] fp32 or Planes, C % 8 == 0) in one pass; var biased (1 / n) or unbiased (1 / (n - 1))."""
+    lib = _lib.load()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    xp, xpl = _fmt(x, "colstats.x")
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    var = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = workspace(2 * lib.cxrk_coldot_ws_bytes(rows, C), x.device)
+    check(lib.cxrk_colstats(xp, xpl, rows, C, _p(mean), _p(var), 1.0 / max(1, rows - 1) if unbiased else 1.0 / rows, _p(ws), ws.numel() * 4,
+                            _stream()), f"cxrk_colstats(rows={rows},C={C})")
+    return mean, var
+
+
 def bn_train_fwd_coeffs(mean, var, gamma, beta, eps: float, n: int, momentum: float = 0.0, rmean=None, rvar=None):
     """(scale, shift, rstd) of a train-mode BatchNorm from its batch statistics (var: biased); updates the running statistics in place
     (r = (1 - momentum) r + momentum stat, unbiased variance) when given."""
@@ -497,8 +511,8 @@ def bn_apply(z, scale, shift, residual=None, relu: bool = True, want_mask: bool 
     return y, mask
 
 
-def coldot(a, b) -> torch.Tensor:
-    """out[c] = sum_rows a[r, c] * b[r, c]; a, b: [..., C] fp32 or Planes (formats may differ)."""
+def coldot(a, b, bshift=None) -> torch.Tensor:
+    """out[c] = sum_rows a[r, c] * (b[r, c] - bshift[c]); a, b: [..., C] fp32 or Planes (formats may differ); bshift: fp32 [C] or None."""
     lib = _lib.load()
     C = a.shape[-1]
     rows = a.numel() // C
@@ -508,12 +522,12 @@ def coldot(a, b) -> torch.Tensor:
     bp, bpl = _fmt(b, "coldot.b")
     out = torch.empty(C, dtype=torch.float32, device=a.device)
     ws = workspace(lib.cxrk_coldot_ws_bytes(rows, C), a.device)
-    check(lib.cxrk_coldot(ap, apl, bp, bpl, rows, C, _p(out), _p(ws), ws.numel() * 4, _stream()), "cxrk_coldot")
+    check(lib.cxrk_coldot(ap, apl, bp, bpl, _p(_vec(bshift, C, "coldot.bshift")) if bshift is not None else None, rows, C, _p(out), _p(ws), ws.numel() * 4, _stream()), "cxrk_coldot")
     return out
 
 
 def bn_train_bwd_coeffs(gamma, mean, rstd, sumdy, dot, n: int, dgamma, dbeta, accumulate: bool):
-    """dgamma (+)= rstd (dot - mean sumdy), dbeta (+)= sumdy; returns (A, B, Cc) with dz = A dy + B + Cc z."""
+    """dot = sum dy (z - mean) (coldot(dy, z, mean)); dgamma (+)= rstd dot, dbeta (+)= sumdy; returns (A, B, Cc), dz = A dy + B + Cc z."""
     lib = _lib.load()
     C = gamma.numel()
     for nme, t in (("gamma", gamma), ("mean", mean), ("rstd", rstd), ("sumdy", sumdy), ("dot", dot), ("dgamma", dgamma), ("dbeta", dbeta)):

@@ -254,6 +254,67 @@ def test_planes_roundtrip_and_colsum():
     close(K.colsum(p, torch.empty(136, device=DEV)), x.sum(0), tol=2e-5, what="colsum planes")
 
 
+@pytest.mark.parametrize("rows,C,planes", [(5000, 64, False), (5000, 64, True), (777, 264, True), (1, 8, False), (70000, 16, True)])
+def test_train_mode_batchnorm_kernels(rows, C, planes):
+    """csrc/bn_train.hip against torch.nn.functional.batch_norm(training=True) + autograd (float64 on the CPU): one-pass statistics
+    with a LARGE common offset (the case a naive sum-of-squares loses), apply + ReLU decision bits, running-stat update, dgamma /
+    dbeta / dz."""
+    g = torch.Generator().manual_seed(rows + C)
+    z = torch.randn(rows, C, generator=g) * torch.linspace(0.1, 3.0, C) + torch.linspace(-300.0, 300.0, C)
+    res = torch.randn(rows, C, generator=g)
+    dy = torch.randn(rows, C, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm0, rv0 = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    wrap = _pl if planes else (lambda t: t.contiguous().to(DEV))
+    zd = wrap(z)
+    zq = zd.float().cpu() if planes else z                   # the values the kernels see (planes storage rounds to ~2^-17)
+    if rows == 1:                                            # torch refuses one value per channel; mean = z, variance 0
+        mean, var = K.colstats(zd)
+        close(mean, zq[0], tol=1e-6, what="mean of one row")
+        assert float(var.abs().max()) == 0.0
+        return
+    # reference in float64
+    z64 = zq.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    y64 = F.relu(F.batch_norm(z64, rm, rv, g64, b64, training=True, momentum=0.1, eps=1e-5) + res.double())
+    # kernels
+    mean, var = K.colstats(zd)
+    close(mean, zq.double().mean(0).float(), tol=1e-6, what="mean")
+    close(var, zq.double().var(0, unbiased=False).float(), tol=2e-5, what="biased var")
+    close(K.colstats(zd, unbiased=True)[1], zq.double().var(0, unbiased=True).float(), tol=2e-5, what="unbiased var")
+    rmd, rvd = rm0.to(DEV), rv0.to(DEV)
+    scale, shift, rstd = K.bn_train_fwd_coeffs(mean, var, gamma.to(DEV), beta.to(DEV), 1e-5, rows, 0.1, rmd, rvd)
+    y, mask = K.bn_apply(zd, scale, shift, residual=wrap(res), relu=True, want_mask=True)
+    yf = y.float() if planes else y
+    close(yf, y64.detach().float(), tol=3e-5, what="y")
+    close(rmd, rm.float(), tol=2e-6, what="running_mean")
+    close(rvd, rv.float(), tol=2e-5, what="running_var")
+    bits = torch.from_numpy(np.unpackbits(mask.cpu().numpy(), axis=1, bitorder="little")[:, :C].astype(bool))
+    agree = (bits == (y64.detach() > 0)).float().mean()
+    assert agree > 0.9999, agree                              # decisions within rounding of zero may differ
+    # backward: dy masked by the kernel's own decisions, as image_encoder._backward does
+    dym = dy * bits
+    dyd = wrap(dym)
+    dyq = dyd.float().cpu() if planes else dym
+    sumdy = K.colsum(dyd, torch.empty(C, device=DEV))
+    close(K.coldot(dyd, zd), (dyq.double() * zq.double()).sum(0).float(), tol=2e-5, what="plain dot")
+    dot = K.coldot(dyd, zd, mean)
+    dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    A, B, Cc = K.bn_train_bwd_coeffs(gamma.to(DEV), mean, rstd, sumdy, dot, rows, dgam, dbet, False)
+    dz = K.bn_train_dz(dyd, zd, A, B, Cc)
+    dzf = dz.float() if planes else dz
+    # reference with the same decisions
+    z64b = zq.double().requires_grad_(True)
+    g64b, b64b = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    F.batch_norm(z64b, None, None, g64b, b64b, training=True, eps=1e-5).backward(dyq.double())
+    # the products are centred (z - mean) before they are summed: what is left of the +-300 offsets is the rounding of the fp32
+    # mean itself (300 * 2^-24 against a spread of 0.1 .. 3), 1e-4 of dgamma at the narrow channels
+    close(dbet, b64b.grad.float(), tol=2e-5, what="dbeta")
+    close(dgam, g64b.grad.float(), tol=3e-4, what="dgamma")
+    close(dzf, z64b.grad.float(), tol=1e-4, what="dz")
+
+
 PL_GEMMS = [(200, 136, 72), (1024, 128, 768), (64, 256, 128), (512, 64, 264), (4096, 512, 512), (8192, 768, 256)]
 
 
