@@ -1,6 +1,7 @@
 // ResNet-50 image-encoder kernels, data gradient: implicit-GEMM transposed convolution (stride-2 layers by output-parity classes),
 // ReLU mask, identity-branch gradient and the fused BatchNorm beta-gradient column sums in the epilogue.
 #include "conv_common.h"
+#include "conv_halo.h"
 
 using namespace cxrk;
 
@@ -39,6 +40,8 @@ static int dgrad_tiles(int rows, int C, long K, bool planes) {
 
 // number of per-wave partial rows the fused column sum of a data-gradient launch produces (all parity classes)
 static long dgrad_colsum_parts(int N, int H, int W, int C, int stride, int Ko, int R, int S, int pad, bool planes) {
+  if (planes && halo_applies(H, W, Ko, C, R, S, stride, pad) && !use_wide256(N * H * W, C, (long)R * S * Ko, 1, planes, WIDE_MINK_DGRAD))
+    return (long)ceil_div(N * H * W, HALO_TM) * 8;      // conv_halo.h: one partial row per 32-row half of a 64-row block
   if (stride == 1) return dgrad_tiles(N * H * W, C, (long)R * S * Ko, planes);
   long t = 0;
   for (int ph = 0; ph < 2; ++ph)
@@ -72,6 +75,11 @@ static int conv_bwd_data_impl(const typename FMT::T* dy, long dyplane, const typ
         DmaConvDgradKC<256, 8>::P pa{dy, g, M, K, dyplane}; DmaConvFilterMC<256, 8>::P pb{w, g, C, K, wplane};
         rc = launch_gemm_pw<Pw256, DmaConvDgradKC<256, 8>, DmaConvFilterMC<256, 8>>(pa, pb, ep, M, C, K, 1, stream);
       } else return CXRK_ERR_UNSUPPORTED;
+    } else if (FMT::PLANES && halo_applies(H, W, Ko, C, R, S, stride, pad)) {   // 64 -> 64: the dy window resident in LDS (conv_halo.h)
+      if constexpr (FMT::PLANES) {
+        DmaConvFilterMC<64, 4>::P pb{w, g, C, K, wplane};
+        rc = launch_conv3x3_halo<DmaConvFilterMC<64, 4>, true>(dy, dyplane, pb, ep, M, C, H, W, stream);
+      } else rc = CXRK_ERR_UNSUPPORTED;
     } else if (C <= 64) {
       if constexpr (FMT::PLANES) {
         DmaConvDgradKC<256, 4>::P pa{dy, g, M, K, dyplane}; DmaConvFilterMC<64, 4>::P pb{w, g, C, K, wplane};
@@ -163,7 +171,7 @@ static int finish_colsum(float* ws, long np, int C, float* sums, hipStream_t str
 extern "C" size_t cxrk_conv_bwd_data_colsum_ws_bytes(int N, int H, int W, int C, int stride) {
   // upper bound over the tile choices (the exact count needs the filter shape): 256-row tiles, 4 slabs each
   long parts = 0;
-  if (stride == 1) parts = (long)ceil_div((long)N * H * W, 256) * 4;
+  if (stride == 1) parts = (long)ceil_div((long)N * H * W, 256) * 8;   // 8: the window-resident 3x3 kernel's halves (conv_halo.h)
   else
     for (int ph = 0; ph < 2; ++ph)
       for (int pw = 0; pw < 2; ++pw) { const int Hs = (H - ph + 1) / 2, Ws = (W - pw + 1) / 2; if (Hs > 0 && Ws > 0) parts += (long)ceil_div((long)N * Hs * Ws, 256) * 4; }

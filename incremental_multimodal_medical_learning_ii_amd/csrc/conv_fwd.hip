@@ -1,6 +1,7 @@
 // ResNet-50 image-encoder kernels, forward: NHWC implicit-GEMM convolution + eval-mode BatchNorm (folded) + residual + ReLU on the
 // shared MFMA mainloops.  Reference semantics: health_multimodal/image/model/resnet.py:25-47, torchvision Bottleneck (v1.5).
 #include "conv_common.h"
+#include "conv_halo.h"
 
 using namespace cxrk;
 
@@ -24,7 +25,12 @@ static int conv_fwd_impl(const typename FMT::T* x, long xplane, const typename F
       rc = launch_gemm_pw<Pw256, DmaConvIm2colKC<256, 8>, DmaDenseKC<256, 8>>(pa, pb, ep, M, Ko, K, 1, stream);
     } else return CXRK_ERR_UNSUPPORTED;
   } else if (tapwise) {
-    if (Ko <= 64) {
+    if (FMT::PLANES && halo_applies(H, W, C, Ko, R, S, stride, pad)) {   // the 56 x 56 64 -> 64 layers: window resident in LDS
+      if constexpr (FMT::PLANES) {
+        DmaDenseKC<64, 4>::P pb{w, (long)K, Ko, K, wplane};
+        rc = launch_conv3x3_halo<DmaDenseKC<64, 4>, false>(x, xplane, pb, ep, M, Ko, H, W, stream);
+      } else rc = CXRK_ERR_UNSUPPORTED;
+    } else if (Ko <= 64) {
       if constexpr (FMT::PLANES) {
         DmaConvIm2colKC<256, 4>::P pa{x, g, M, K, xplane}; DmaDenseKC<64, 4>::P pb{w, (long)K, Ko, K, wplane};
         rc = launch_gemm_pw<Pw256x64, DmaConvIm2colKC<256, 4>, DmaDenseKC<64, 4>>(pa, pb, ep, M, Ko, K, 1, stream);

@@ -120,11 +120,16 @@ constexpr bool epi_two_fp32_sides(unsigned f) { return (f & EF_RES_F32) != 0u &&
 // half h + 1 are requested as soon as the same pass of half h has been stored, so only the first half's loads are waited for at
 // full memory latency; the un-pipelined form (generic feature set, register-staged kernels) loads the side inputs of a half and
 // consumes them at once — a round trip per half with nothing of this wave in between.
-template <unsigned F, int NSUB, bool PIPE>
+// PAIR (conv_halo.h): two waves share one 64 x 64 output block, wave `psel` holding its columns 32 psel .. +31 (acc[0][i][0], all
+// 64 rows).  Both stage their column block of BOTH 32-row halves into the pair's shared staging area `st` ([2 halves][32][64]
+// fp32), meet at the workgroup barrier (every wave of the block must call this), and wave psel then finishes half psel alone:
+// the 64 x 64 block's epilogue runs on two waves.  Column sums: one partial row per (block, half) — `part` is that row.
+template <unsigned F, int NSUB, bool PIPE, bool PAIR = false>
 __device__ __forceinline__ void epi_rows(f32x16 (*acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0, int col0,
-                                         int part, int z, int lane) {
+                                         int part, int z, int lane, int psel = 0) {
   constexpr bool GEN = (F & EF_GENERIC) != 0u;
   static_assert(!(GEN && PIPE), "the generic feature set is not pipelined");
+  static_assert(!PAIR || (NSUB == 1 && !PIPE), "the pair form: one 64-row block, un-pipelined");
   const bool outpl = EH(EF_OUTPL, ep.Cp != nullptr), has_bias = EH(EF_BIAS, ep.bias != nullptr);
   const bool res_f32 = EH(EF_RES_F32, ep.R != nullptr), res_pl = EH(EF_RES_PL, ep.Rp != nullptr);
   const bool relu = EH(EF_RELU, ep.act == 1), gelu = EH(EF_GELU, ep.act == 2);
@@ -213,7 +218,7 @@ __device__ __forceinline__ void epi_rows(f32x16 (*acc)[2][2], const EpiParams& e
   // values and stores of pass ua of half hh, from the staged accumulators and the side inputs in slot u of `sd`
   auto finish_pass = [&](const Side& sd, int u, int hh, int ua) {
     {
-      const float* sp = st + (ua * 8 + rq) * 64;
+      const float* sp = st + (PAIR ? psel * 2048 : 0) + (ua * 8 + rq) * 64;
       const float4 s0 = *reinterpret_cast<const float4*>(sp + cA), s1 = *reinterpret_cast<const float4*>(sp + cB);
       float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
       const unsigned rowo = sd.rowo[u];
@@ -308,7 +313,23 @@ __device__ __forceinline__ void epi_rows(f32x16 (*acc)[2][2], const EpiParams& e
 
   constexpr int NHALF = 2 * NSUB;
   Side sd;
-  if constexpr (PIPE) {
+  if constexpr (PAIR) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[i * 2048 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 64 + psel * 32 + r] = acc[0][i][0][e];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int ug = 0; ug < 4; ug += PF) {
+#pragma unroll
+      for (int up = 0; up < PF; ++up) load_side(sd, up, psel, ug + up);
+#pragma unroll
+      for (int up = 0; up < PF; ++up) finish_pass(sd, up, psel, ug + up);
+    }
+    if (colsum) flush_colsum(part);
+  } else if constexpr (PIPE) {
     // slot u holds the side inputs of pass u of the current half; the moment pass u has been combined and stored, the slot is
     // re-requested for pass u of the NEXT half: that load is in flight for a whole half's worth of staging, arithmetic and stores
     // (one set of side-input registers, as in the un-pipelined form)
@@ -367,6 +388,17 @@ __device__ __forceinline__ void epi_pw_dispatch(int kind, f32x16 (*acc)[2][2], c
   else {
     if (kind == KIND) epi_rows<EPI_KINDS[KIND], NSUB, (CXRK_EPI_PIPE != 0) && epi_has_side(EPI_KINDS[KIND]) && !epi_two_fp32_sides(EPI_KINDS[KIND])>(acc, ep, st, M, N, row0, col0, part, z, lane);
     else epi_pw_dispatch<KIND + 1, NSUB>(kind, acc, ep, st, M, N, row0, col0, part, z, lane);
+  }
+}
+
+// The pair form (conv_halo.h): see epi_rows<..., PAIR = true>.
+template <int KIND>
+__device__ __forceinline__ void epi_pair_dispatch(int kind, f32x16 (*acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0,
+                                                  int col0, int part, int lane, int psel) {
+  if constexpr (KIND >= EPI_NKINDS) epi_rows<EF_GENERIC, 1, false, true>(acc, ep, st, M, N, row0, col0, part, 0, lane, psel);
+  else {
+    if (kind == KIND) epi_rows<EPI_KINDS[KIND], 1, false, true>(acc, ep, st, M, N, row0, col0, part, 0, lane, psel);
+    else epi_pair_dispatch<KIND + 1>(kind, acc, ep, st, M, N, row0, col0, part, lane, psel);
   }
 }
 

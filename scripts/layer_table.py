@@ -45,6 +45,8 @@ L = [(56, 64, 64, 1, 1, 1, 0), (56, 64, 64, 3, 1, 3, 0), (56, 64, 256, 1, 1, 4, 
      (14, 1024, 256, 1, 1, 5, 0), (14, 256, 256, 3, 1, 5, 0),
      (14, 1024, 512, 1, 1, 1, 0), (14, 512, 512, 3, 2, 1, 0), (7, 512, 2048, 1, 1, 3, 3), (14, 1024, 2048, 1, 2, 1, 0),
      (7, 2048, 512, 1, 1, 2, 0), (7, 512, 512, 3, 1, 2, 0)]
+if os.environ.get("CXRK_LAYER_ROWS"):      # e.g. CXRK_LAYER_ROWS=1,9: only these entries of L (A/B runs of one kernel)
+    L = [L[int(i)] for i in os.environ["CXRK_LAYER_ROWS"].split(",")]
 rows = []
 for (H, C, Ko, R, st, cnt, nres) in L:
     pad = R // 2

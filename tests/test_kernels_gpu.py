@@ -390,6 +390,9 @@ PL_CONVS = [  # N,H,W,C,Ko,R,stride,pad
     # >= 1 GFLOP: the 256x256 LDS-DMA kernel takes forward / data gradient / weight gradient where both tile dimensions fill
     (16, 28, 28, 128, 128, 3, 1, 1), (32, 28, 28, 256, 256, 3, 2, 1), (64, 14, 14, 256, 1024, 1, 1, 0), (64, 14, 14, 1024, 256, 1, 1, 0),
     (32, 28, 28, 512, 1024, 1, 2, 0),
+    # 3x3 / stride 1 / 64 -> 64: the window-resident kernel (csrc/conv_halo.h): two tiles with a ragged end, the real 56-pixel rows
+    # (36.75 tiles, windows crossing image boundaries), the widest row it takes (58) and the first it leaves to the implicit GEMM (59)
+    (2, 12, 12, 64, 64, 3, 1, 1), (3, 56, 56, 64, 64, 3, 1, 1), (5, 7, 58, 64, 64, 3, 1, 1), (2, 9, 59, 64, 64, 3, 1, 1), (1, 3, 5, 64, 64, 3, 1, 1),
 ]
 
 
