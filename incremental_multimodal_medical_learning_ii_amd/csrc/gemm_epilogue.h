@@ -102,6 +102,11 @@ __device__ __forceinline__ uint4 f4_bits(float a, float b, float c, float d) {
   return make_uint4(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
 }
 
+// (Round 3, tried and NOT kept: the OR over the 8 lanes of a row that assembles the ReLU decision bytes as three DPP steps —
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror — instead of three ds_bpermute round trips.  It took the forward
+// epilogue of conv_halo.h from 6 960 to 5 570 cycles (scripts/tune_halo.hip) and passed the kernel tests and epilogue_check, but
+// the fp32-mode data gradient of tests/test_models_gpu.py::test_image_model_forward_backward then aborted the queue without a
+// message, in a feature set that does not even store decision bits; not understood, so not shipped.)
 // Experiment switch (round 3, measured and NOT kept): 1 = pipeline the side inputs of the LDS-DMA kernels' epilogues (see epi_rows).
 // With it the data-gradient launches of the step took 20.34 instead of 20.45 ms and the step 154.0 instead of 155.3 ms — inside
 // the box-to-box spread — while the 256x256 instantiations went from 249 registers to 256 + 60 spilled (scratch): the epilogue is
