@@ -116,6 +116,13 @@ int cxrk_conv_bn_act_bwd_data_pl(const void* dy, long dyplane, const void* w_sca
                                  long rplane, const unsigned char* maskin, void* dx, long dxplane, int N, int H, int W, int C,
                                  int Ko, int R, int S, int stride, int pad, float* sums, float* ws, size_t ws_bytes,
                                  hipStream_t stream);
+/* The same with a COMPACT residual: planes [N, (H + 1) / 2, (W + 1) / 2, C] = the identity-branch gradient at the pixels with even
+ * (h, w) only (the data gradient of a 1x1 / stride-2 projection shortcut, torchvision Bottleneck.downsample, resnet.py:36-47);
+ * stride must be 1; CXRK_ERR_UNSUPPORTED when the compact tensor exceeds 2 GiB per plane (use the dense form then). */
+int cxrk_conv_bn_act_bwd_data_pl_s2res(const void* dy, long dyplane, const void* w_scaled, long wplane, const void* residual_s2,
+                                 long rplane, const unsigned char* maskin, void* dx, long dxplane, int N, int H, int W, int C,
+                                 int Ko, int R, int S, int stride, int pad, float* sums, float* ws, size_t ws_bytes,
+                                 hipStream_t stream);
 size_t cxrk_conv_wgrad_ws_bytes(int N, int H, int W, int Cpad, int Ko, int R, int S, int stride, int pad);
 int cxrk_conv_bn_act_bwd_params(const float* x, const float* dy, const float* w, const float* scale, const float* rstd,
                                 const float* rmean, const float* sumdy, float* dw, float* dgamma, float* dbeta,

@@ -34,6 +34,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "cxrk_conv_bwd_data_colsum_ws_bytes": (Z, [I, I, I, I, I]),
     "cxrk_conv_bn_act_bwd_data": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, Z, P]),
     "cxrk_conv_bn_act_bwd_data_pl": (I, [P, L, P, L, P, L, P, P, L, I, I, I, I, I, I, I, I, I, P, P, Z, P]),
+    "cxrk_conv_bn_act_bwd_data_pl_s2res": (I, [P, L, P, L, P, L, P, P, L, I, I, I, I, I, I, I, I, I, P, P, Z, P]),
     "cxrk_conv_wgrad_ws_bytes": (Z, [I, I, I, I, I, I, I, I, I]),
     "cxrk_conv_bn_act_bwd_params": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, Z, P]),
     "cxrk_conv_bn_act_bwd_params_pl": (I, [P, L, P, L, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, Z, P]),

@@ -201,12 +201,35 @@ extern "C" int cxrk_conv_bn_act_bwd_data(const float* dy, const float* w_scaled,
 
 // planes storage: dy, w_scaled, residual (optional) and dx are planes; `maskin` (optional) = ReLU decision bits of the unit
 // whose output gradient this is (byte [pixel][C / 8]).
+static int conv_bwd_data_pl_impl(const void* dy, long dyplane, const void* w_scaled, long wplane, const void* residual, long rplane, int res_s2,
+                                 const unsigned char* maskin, void* dx, long dxplane, int N, int H, int W, int C, int Ko, int R, int S,
+                                 int stride, int pad, float* sums, float* ws, size_t ws_bytes, hipStream_t stream);
 extern "C" int cxrk_conv_bn_act_bwd_data_pl(const void* dy, long dyplane, const void* w_scaled, long wplane, const void* residual,
                                             long rplane, const unsigned char* maskin, void* dx, long dxplane, int N, int H, int W,
                                             int C, int Ko, int R, int S, int stride, int pad, float* sums, float* ws,
                                             size_t ws_bytes, hipStream_t stream) {
+  return conv_bwd_data_pl_impl(dy, dyplane, w_scaled, wplane, residual, rplane, 0, maskin, dx, dxplane, N, H, W, C, Ko, R, S, stride, pad, sums, ws,
+                               ws_bytes, stream);
+}
+// The same with a COMPACT residual: planes [N, (H + 1) / 2, (W + 1) / 2, C] holding the identity-branch gradient at the pixels with
+// even (h, w) — what the data gradient of a 1x1 / stride-2 projection shortcut is (a dense [pixels / 4, Ko] x [Ko, C] product);
+// the other pixels receive nothing.  Saves zero-filling, writing and re-reading the 3/4 of that gradient that are zero.
+extern "C" int cxrk_conv_bn_act_bwd_data_pl_s2res(const void* dy, long dyplane, const void* w_scaled, long wplane, const void* residual_s2,
+                                                  long rplane, const unsigned char* maskin, void* dx, long dxplane, int N, int H, int W,
+                                                  int C, int Ko, int R, int S, int stride, int pad, float* sums, float* ws,
+                                                  size_t ws_bytes, hipStream_t stream) {
+  CXRK_CHECK_ARG(residual_s2 && stride == 1);
+  // 32-bit byte offsets into the compact tensor (gemm_epilogue.h)
+  if ((long)N * ((H + 1) / 2) * ((W + 1) / 2) * C * 2 >= (1L << 31)) return CXRK_ERR_UNSUPPORTED;
+  return conv_bwd_data_pl_impl(dy, dyplane, w_scaled, wplane, residual_s2, rplane, 1, maskin, dx, dxplane, N, H, W, C, Ko, R, S, stride, pad, sums,
+                               ws, ws_bytes, stream);
+}
+static int conv_bwd_data_pl_impl(const void* dy, long dyplane, const void* w_scaled, long wplane, const void* residual, long rplane, int res_s2,
+                                 const unsigned char* maskin, void* dx, long dxplane, int N, int H, int W, int C, int Ko, int R, int S,
+                                 int stride, int pad, float* sums, float* ws, size_t ws_bytes, hipStream_t stream) {
   CXRK_CHECK_ARG(dx && (C % 8) == 0);
   EpiParams ep{};
+  if (res_s2) { ep.rs2_on = 1; ep.rs2_H = H; ep.rs2_W = W; ep.rs2_Ho = (H + 1) / 2; ep.rs2_Wo = (W + 1) / 2; }
   ep.Cp = static_cast<unsigned short*>(dx); ep.cplane = dxplane; ep.ldc = C;
   ep.Rp = static_cast<const unsigned short*>(residual); ep.rplane = rplane; ep.ldr = C; ep.alpha = 1.f;
   if (maskin) { ep.maskin = maskin; ep.ldmaskin = C / 8; ep.auxmode = 3; }

@@ -56,6 +56,10 @@ struct EpiParams {
   int kind; // set by launch_gemm: index of the compiled-in feature set (EPI_KINDS), or -1 = generic
   // diagnostics only (scripts/tune_pw.hip): per-block s_memtime stamps [block][8]; null in the library
   unsigned long long* stamps;
+  // optional COMPACT planes residual (the data gradient of a 1x1 / stride-2 projection shortcut; LDS-DMA kernels only): the output
+  // rows are the pixels of [N, rs2_H, rs2_W], Rp holds rows for the pixels with even (h, w) only, as [N, rs2_Ho, rs2_Wo] — the
+  // other pixels get nothing.  (At the end of the block: the register-staged kernels' code does not move, see gemm_epilogue.h epi64.)
+  int rs2_on, rs2_H, rs2_W, rs2_Ho, rs2_Wo;
 };
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -523,6 +527,7 @@ static inline bool prep_epilogue(EpiParams& e, int M, int N, int splitk) {
   e.kind = epi_kind(epi_flags(e));
   // fp32-output feature sets use the 4 + 4 column lane map, whose two column groups must be inside or outside the tensor together
   if (e.kind >= 0 && (EPI_KINDS[e.kind] & (EF_OUTPL | EF_AUX_MASK | EF_MASKOUT)) == 0u && (N % 64) != 0) e.kind = -1;
+  if (e.rs2_on && !(e.Rp && e.Cp && e.rs2_H > 0 && e.rs2_W > 0 && (long)e.rs2_Ho * e.rs2_Wo > 0)) return false;
   if (e.pl) {   // planes / mask operands exist in the fast epilogue only
     if (!e.fast) return false;
     if ((e.C != nullptr) == (e.Cp != nullptr)) return false;           // exactly one output format
@@ -548,6 +553,7 @@ static int launch_gemm(const typename LA::P& pa, const typename LB::P& pb, const
   dim3 grid((unsigned)(nMt * nNt * splitk), 1, 1);
   EpiParams e = ep;
   if (!prep_epilogue(e, M, N, splitk)) return CXRK_ERR_ARG;
+  if (e.rs2_on) return CXRK_ERR_UNSUPPORTED;   // the compact stride-2 residual exists in the LDS-DMA kernels' epilogue only
   // split-bf16 only where it pays and is well conditioned: small problems (adapters, heads: < 1 GFLOP) and launches the
   // caller marks exact (the stem convolution: an all-positive input makes its weight gradient a cancelling sum) stay fp32.
   // Pre-split ("planes") operands exist in the split-bf16 format only: they always take the split mainloop.

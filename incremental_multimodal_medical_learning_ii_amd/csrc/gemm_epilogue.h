@@ -34,6 +34,7 @@ enum : unsigned {
   EF_MASKOUT = 1u << 10,   // store the ReLU decision bits
   EF_COLSUM = 1u << 11,    // per-wave column sums of the stored values
   EF_REMAP = 1u << 12,     // output-row remap (stride-2 dgrad parity class)
+  EF_RES_S2 = 1u << 13,    // the planes residual is compact: rows for the even (h, w) pixels of the output only
   EF_GENERIC = 1u << 31,   // every feature decided at run time
 };
 
@@ -60,6 +61,7 @@ constexpr unsigned EPI_KINDS[] = {
     EF_RES_F32,                                                  // 18 fp32 mode: data gradient + residual gradient
     EF_OUTPL | EF_BIAS | EF_RELU,                                // 19 stem conv + BN + ReLU (its mask is the sign of the pooled value)
     EF_OUTPL | EF_AUX_GELU | EF_COLSUM,                          // 20 gradient through GELU + its column sums (FFN-up bias gradient)
+    EF_OUTPL | EF_RES_PL | EF_RES_S2 | EF_AUX_MASK | EF_COLSUM,  // 21 kind 10 with the identity-branch gradient of a stride-2 projection (compact)
 };
 constexpr int EPI_NKINDS = (int)(sizeof(EPI_KINDS) / sizeof(EPI_KINDS[0]));
 
@@ -79,6 +81,7 @@ static inline unsigned epi_flags(const EpiParams& e) {
   if (e.maskout) f |= EF_MASKOUT;
   if (e.colsum_part) f |= EF_COLSUM;
   if (e.rm_on) f |= EF_REMAP;
+  if (e.rs2_on) f |= EF_RES_S2;
   return f;
 }
 static inline int epi_kind(unsigned flags) {
@@ -129,7 +132,9 @@ constexpr bool epi_two_fp32_sides(unsigned f) { return (f & EF_RES_F32) != 0u &&
 // 64 rows).  Both stage their column block of BOTH 32-row halves into the pair's shared staging area `st` ([2 halves][32][64]
 // fp32), meet at the workgroup barrier (every wave of the block must call this), and wave psel then finishes half psel alone:
 // the 64 x 64 block's epilogue runs on two waves.  Column sums: one partial row per (block, half) — `part` is that row.
-template <unsigned F, int NSUB, bool PIPE, bool PAIR = false>
+// S2RES: the compact stride-2 residual (EF_RES_S2) is compiled in.  Only the LDS-DMA kernels (epi_pw_dispatch / epi_pair_dispatch)
+// carry it: the register-staged fp32 / x3 kernels never see such a launch, and their code must not grow (see the note at epi64).
+template <unsigned F, int NSUB, bool PIPE, bool PAIR = false, bool S2RES = true>
 __device__ __forceinline__ void epi_rows(f32x16 (*acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0, int col0,
                                          int part, int z, int lane, int psel = 0) {
   constexpr bool GEN = (F & EF_GENERIC) != 0u;
@@ -141,6 +146,7 @@ __device__ __forceinline__ void epi_rows(f32x16 (*acc)[2][2], const EpiParams& e
   const bool aux_sign = EH(EF_AUX_SIGN, ep.auxmode == 1), aux_gelu = EH(EF_AUX_GELU, ep.auxmode == 2), aux_mask = EH(EF_AUX_MASK, ep.auxmode == 3);
   const bool has_c2 = EH(EF_C2, ep.C2 != nullptr), maskout = EH(EF_MASKOUT, ep.maskout != nullptr);
   const bool colsum = EH(EF_COLSUM, ep.colsum_part != nullptr), remap = EH(EF_REMAP, ep.rm_on != 0);
+  const bool res_s2 = S2RES && EH(EF_RES_S2, ep.rs2_on != 0);   // (planes output only: prep_epilogue)
   const bool nt = ep.nt != 0;
 
   const int r = lane & 31, h = lane >> 5;
@@ -176,8 +182,9 @@ __device__ __forceinline__ void epi_rows(f32x16 (*acc)[2][2], const EpiParams& e
   float* Cf = ep.C ? ep.C + (long)z * ep.slab_stride : nullptr;
   const __amdgpu_buffer_rsrc_t d_out = tile_rsrc(outpl ? (const void*)(ep.Cp + rbase * ep.ldc + col0) : (const void*)(Cf + rbase * ep.ldc + col0));
   const __amdgpu_buffer_rsrc_t d_out2 = tile_rsrc(outpl ? (const void*)(ep.Cp + ep.cplane + rbase * ep.ldc + col0) : (const void*)nullptr, outpl);
-  const __amdgpu_buffer_rsrc_t d_res = tile_rsrc(res_pl ? (const void*)(ep.Rp + rbase * ep.ldr + col0) : (const void*)(ep.R + rbase * ep.ldr + col0), res_pl || res_f32);
-  const __amdgpu_buffer_rsrc_t d_res2 = tile_rsrc(res_pl ? (const void*)(ep.Rp + ep.rplane + rbase * ep.ldr + col0) : (const void*)nullptr, res_pl);
+  const long rres = res_s2 ? 0 : rbase;   // the compact residual is addressed from its first row
+  const __amdgpu_buffer_rsrc_t d_res = tile_rsrc(res_pl ? (const void*)(ep.Rp + rres * ep.ldr + col0) : (const void*)(ep.R + rbase * ep.ldr + col0), res_pl || res_f32);
+  const __amdgpu_buffer_rsrc_t d_res2 = tile_rsrc(res_pl ? (const void*)(ep.Rp + ep.rplane + rres * ep.ldr + col0) : (const void*)nullptr, res_pl);
   const __amdgpu_buffer_rsrc_t d_aux = tile_rsrc(ep.aux + rbase * ep.ldaux + col0, aux_sign || aux_gelu);
   const __amdgpu_buffer_rsrc_t d_c2 = tile_rsrc(ep.C2 + rbase * ep.ldc2 + col0, has_c2);
   const __amdgpu_buffer_rsrc_t d_min = tile_rsrc(ep.maskin + rbase * ep.ldmaskin + (col0 >> 3), aux_mask);
@@ -205,7 +212,13 @@ __device__ __forceinline__ void epi_rows(f32x16 (*acc)[2][2], const EpiParams& e
           const uint2 ha = buf_load8(d_res, oa), hb = buf_load8(d_res, oa + DB2), la = buf_load8(d_res2, oa), lb = buf_load8(d_res2, oa + DB2);
           sd.r0v[u] = make_uint4(ha.x, ha.y, hb.x, hb.y); sd.r1v[u] = make_uint4(la.x, la.y, lb.x, lb.y);
         } else {
-          const unsigned o = ((rowo * (unsigned)ep.ldr + cA) * 2u) | sd.dead[u] | deadA;
+          unsigned o = ((rowo * (unsigned)ep.ldr + cA) * 2u) | sd.dead[u] | deadA;
+          if (res_s2) {   // output pixel (n, h, w) -> compact row (n, h / 2, w / 2) when h and w are even, else no residual
+            const int gr = grow < M ? grow : M - 1;
+            const int w_ = gr % ep.rs2_W; const int t_ = gr / ep.rs2_W; const int h_ = t_ % ep.rs2_H; const int n_ = t_ / ep.rs2_H;
+            const unsigned crow = (unsigned)((n_ * ep.rs2_Ho + (h_ >> 1)) * ep.rs2_Wo + (w_ >> 1));
+            o = ((crow * (unsigned)ep.ldr + cA) * 2u) | (((w_ | h_) & 1) ? VOFF_OOB : 0u) | sd.dead[u] | deadA;
+          }
           sd.r0v[u] = buf_load16(d_res, o); sd.r1v[u] = buf_load16(d_res2, o);
         }
       } else if (res_f32) {
@@ -369,16 +382,24 @@ __device__ __forceinline__ void epi_rows(f32x16 (*acc)[2][2], const EpiParams& e
 }
 #undef EH
 
+// The register-staged kernels (gemm_f32_kernel, gemm_x3_kernel).  Their code is kept exactly as it was before the compact stride-2
+// residual existed (S2RES = false, and the kinds that carry EF_RES_S2 fall through to the generic set, which a launch with
+// rs2_on never reaches here: launch_gemm refuses it): twice in round 3 an addition to this file that only touched feature sets
+// the exact-fp32 mode never runs (a DPP lane-OR in the ReLU-bits path; this residual) made fp32-mode tests fail — an aborted queue
+// in one build, one wrong beta gradient in another, deterministic per build and dependent on the order of the tests, correct again
+// with the addition removed.  Not understood (the kernels hold all 21 feature sets inline and are tens of thousands of
+// instructions long; a code-size dependent miscompilation is the suspicion), so the fp32 kernels are not touched.
 template <unsigned F>
 __device__ __forceinline__ void epi64(f32x16 (&acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0, int col0,
                                       int part, int z, int lane) {
-  epi_rows<F, 1, false>(&acc, ep, st, M, N, row0, col0, part, z, lane);
+  epi_rows<F, 1, false, false, false>(&acc, ep, st, M, N, row0, col0, part, z, lane);
 }
 
 template <int KIND>
 __device__ __forceinline__ void epi64_dispatch(int kind, f32x16 (&acc)[2][2], const EpiParams& ep, float* st, int M, int N, int row0,
                                                int col0, int part, int z, int lane) {
   if constexpr (KIND >= EPI_NKINDS) epi64<EF_GENERIC>(acc, ep, st, M, N, row0, col0, part, z, lane);
+  else if constexpr ((EPI_KINDS[KIND] & EF_RES_S2) != 0u) epi64_dispatch<KIND + 1>(kind, acc, ep, st, M, N, row0, col0, part, z, lane);
   else {
     if (kind == KIND) epi64<EPI_KINDS[KIND]>(acc, ep, st, M, N, row0, col0, part, z, lane);
     else epi64_dispatch<KIND + 1>(kind, acc, ep, st, M, N, row0, col0, part, z, lane);

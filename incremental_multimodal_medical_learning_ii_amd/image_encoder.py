@@ -34,6 +34,8 @@ layout — the flat gradient buffer of `optim._FlatOptimizer` — so autograd ha
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -283,14 +285,16 @@ def _unit_params_bwd(i, s, fold, p, bufs, x, dy, sumdy, N, H, W, sink: GradSink,
         K.conv_bwd_params(x, dy, *args, s.cin, s.cpad, s.cout, s.k, s.k, s.stride, s.pad)
 
 
-def _dgrad(i, s, fold, dy, residual, relu, N, H, W, pl, want_sums):
+def _dgrad(i, s, fold, dy, residual, relu, N, H, W, pl, want_sums, residual_s2=False):
     """Data gradient of unit i, masked by `relu` (planes mode: the bit mask of the tensor the gradient flows into; fp32 mode:
-    that tensor itself).  want_sums: also the column sums of the result (-> (dx, sums[C]))."""
+    that tensor itself).  want_sums: also the column sums of the result (-> (dx, sums[C])).  residual_s2 (planes mode): the
+    residual is the compact gradient of a stride-2 projection shortcut (kernels.conv1x1_s2_bwd_data_compact_pl)."""
     dev = fold.vec.device
     sums = torch.empty(s.cpad, dtype=torch.float32, device=dev) if want_sums else None
     if pl:
         dx = Planes.empty(N, H, W, s.cpad, device=dev)
-        K.conv_bwd_data_pl(dy, fold.ws(i, s), residual, relu, dx, N, H, W, s.cpad, s.cout, s.k, s.k, s.stride, s.pad, sums)
+        K.conv_bwd_data_pl(dy, fold.ws(i, s), residual, relu, dx, N, H, W, s.cpad, s.cout, s.k, s.k, s.stride, s.pad, sums,
+                           residual_s2=residual_s2)
     else:
         dx = torch.empty(N, H, W, s.cpad, dtype=torch.float32, device=dev)
         K.conv_bwd_data(dy, fold.ws(i, s), residual, relu, dx, N, H, W, s.cpad, s.cout, s.k, s.k, s.stride, s.pad, sums)
@@ -409,14 +413,23 @@ def _backward(specs, blocks, p, bufs, state, demb: Optional[torch.Tensor], dpatc
             sd = specs[blk["ds"]]
             gd, gsd = through_bn(blk["ds"], sd, g, gs)
             params_bwd(blk["ds"], sd, cur, gd, gsd, N, hi, wi, pl)
-            res = _dgrad(blk["ds"], sd, fold, gd, None, None, N, hi, wi, pl, False)
+            res = None
+            if pl and sd.k == 1 and sd.stride == 2 and sd.pad == 0 and os.environ.get("CXRK_S2RES", "1") != "0":
+                # a stride-2 projection: its data gradient is non-zero at the even pixels only -> compact [N, hi/2, wi/2, C], added
+                # by the epilogue of conv1's data gradient at those pixels (instead of zero-filling, writing and re-reading a
+                # full-resolution tensor that is 3/4 zeros: 12.8 -> 2.8 GB per step at batch 1024)
+                res = K.conv1x1_s2_bwd_data_compact_pl(gd, fold.ws(blk["ds"], sd), N, hi, wi, sd.cpad, sd.cout)
+                res_s2 = res is not None
+            if res is None:
+                res = _dgrad(blk["ds"], sd, fold, gd, None, None, N, hi, wi, pl, False)
+                res_s2 = False
             del gd
         else:
-            res = g
+            res, res_s2 = g, False
         if bi > 0:
-            g, gs = _dgrad(blk["c1"], s1, fold, d1, res, relu_of_block_out(bi - 1), N, hi, wi, pl, True)
+            g, gs = _dgrad(blk["c1"], s1, fold, d1, res, relu_of_block_out(bi - 1), N, hi, wi, pl, True, residual_s2=res_s2)
         else:   # the block input is the max-pool output: its ReLU (the stem's) is applied by the max-pool backward
-            g, gs = _dgrad(blk["c1"], s1, fold, d1, res, None, N, hi, wi, pl, False), None
+            g, gs = _dgrad(blk["c1"], s1, fold, d1, res, None, N, hi, wi, pl, False, residual_s2=res_s2), None
         del d1, res
         binfo[bi] = None
         if on_grads_ready is not None and blk["ds"] is not None and bi > 0:

@@ -677,8 +677,14 @@ def conv_fwd_pl(x, w_scaled, shift, residual: Optional[Planes], y: Planes, masko
 
 
 def conv_bwd_data_pl(dy: Planes, w_scaled: Planes, residual: Optional[Planes], maskin, dx: Planes, N, H, W, C, Ko, R, S, stride, pad,
-                     sums=None):
+                     sums=None, residual_s2: bool = False):
+    """dx = mask(conv^T(dy, w_scaled) + residual) on planes operands (+ column sums of dx).  residual_s2: `residual` is COMPACT,
+    [N, (H+1)//2, (W+1)//2, C] = the identity-branch gradient at the even (h, w) pixels only (what a 1x1 / stride-2 projection
+    shortcut's data gradient is: see `conv1x1_s2_bwd_data_compact_pl`); the other pixels receive nothing."""
     lib = _lib.load()
+    if residual_s2:
+        if residual is None or tuple(residual.shape) != (N, (H + 1) // 2, (W + 1) // 2, C):
+            raise ValueError(f"conv_bwd_data_pl: compact residual must be [N, (H+1)//2, (W+1)//2, C], got {None if residual is None else tuple(residual.shape)}")
     ws = workspace(lib.cxrk_conv_bwd_data_colsum_ws_bytes(N, H, W, C, stride), dy.device) if sums is not None else None
     ev = None
     if profiler.on:
@@ -686,15 +692,31 @@ def conv_bwd_data_pl(dy: Planes, w_scaled: Planes, residual: Optional[Planes], m
         fl = 2.0 * N * Ho * Wo * Ko * R * S * C
         la, lb, Ml, Kl, sub = _dgrad_label(N, H, W, Ko, R, S, stride)
         ev = profiler.bracket(_label(la, lb, "4,1" if C <= 64 else "2,2", Ml, C, Kl, 1, 2, planes=True), fl,
-                              4.0 * (N * Ho * Wo * Ko + Ko * R * S * C + N * H * W * C * (1 + (residual is not None)))
+                              4.0 * (N * Ho * Wo * Ko + Ko * R * S * C + N * H * W * C * (1 + (0.0 if residual is None else 0.25 if residual_s2 else 1.0)))
                               + (N * H * W * C / 8.0 if maskin is not None else 0.0), sub)
-    rc = lib.cxrk_conv_bn_act_bwd_data_pl(dy.ptr(), dy.plane, w_scaled.ptr(), w_scaled.plane, residual.ptr() if residual is not None else None,
+    fn = lib.cxrk_conv_bn_act_bwd_data_pl_s2res if residual_s2 else lib.cxrk_conv_bn_act_bwd_data_pl
+    rc = fn(dy.ptr(), dy.plane, w_scaled.ptr(), w_scaled.plane, residual.ptr() if residual is not None else None,
                                           residual.plane if residual is not None else 0, _p(maskin), dx.ptr(), dx.plane, N, H, W, C, Ko, R, S,
                                           stride, pad, _p(sums), _p(ws), ws.numel() * 4 if ws is not None else 0, _stream())
     if ev is not None:
         ev.record()
-    check(rc, f"cxrk_conv_bn_act_bwd_data_pl(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
+    check(rc, f"cxrk_conv_bn_act_bwd_data_pl{'_s2res' if residual_s2 else ''}(N={N},H={H},W={W},C={C},Ko={Ko},R={R},s={stride})")
     return dx
+
+
+def conv1x1_s2_bwd_data_compact_pl(dy: Planes, w_scaled: Planes, N, H, W, C, Ko) -> Optional[Planes]:
+    """Data gradient of a 1x1 / stride-2 / pad-0 convolution in COMPACT form: only the input pixels with even (h, w) receive
+    anything, dx[n, 2a, 2b, :] = dy[n, a, b, :] @ w — a dense [N*Ho*Wo, Ko] x [Ko, C] product, returned as [N, Ho, Wo, C] for
+    `conv_bwd_data_pl(..., residual_s2=True)`.  None when the compact tensor is too large for that epilogue's 32-bit offsets
+    (the caller then takes the dense form)."""
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    if N * Ho * Wo * C * 2 >= (1 << 31):
+        return None
+    if tuple(dy.shape) not in ((N, Ho, Wo, Ko), (N * Ho * Wo, Ko)) or tuple(w_scaled.shape) != (Ko, C):
+        raise ValueError(f"conv1x1_s2_bwd_data_compact_pl: dy {tuple(dy.shape)}, w {tuple(w_scaled.shape)} for N={N},H={H},W={W},C={C},Ko={Ko}")
+    out = Planes.empty(N * Ho * Wo, C, device=dy.device)
+    linear_bwd_data_pl(dy.view(N * Ho * Wo, Ko), w_scaled, out=out)
+    return out.view(N, Ho, Wo, C)
 
 
 def conv_bwd_params_pl(x: Planes, dy: Planes, w, scale, rstd, rmean, sumdy, dw, dgamma, dbeta, accumulate, N, H, W, C, Ko, R, S, stride, pad):

@@ -450,6 +450,46 @@ def test_planes_conv_bn_relu_fwd_bwd(cfg, wide):
         close(sums, ref.double().reshape(-1, C).sum(0).float(), tol=3e-4, what="planes dgrad column sums")
 
 
+@pytest.mark.parametrize("N,H,W,C,Ko,R", [(3, 8, 8, 256, 64, 1), (2, 7, 9, 128, 64, 1), (2, 12, 12, 64, 64, 3), (4, 28, 28, 512, 128, 1)])
+def test_planes_dgrad_compact_stride2_residual(N, H, W, C, Ko, R, wide):
+    """The data gradient with the identity-branch gradient of a stride-2 projection given COMPACT ([N, H/2, W/2, C], even pixels only)
+    equals, bit for bit, the one with the same values scattered into a full-resolution residual (zeros elsewhere): output, column
+    sums — and the compact gradient itself equals the even pixels of the dense 1x1 / stride-2 data gradient."""
+    g = torch.Generator().manual_seed(N * H + C)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    # (1) the projection's data gradient: dense form vs compact form
+    Kd = 2 * C
+    gd = _pl(torch.randn(N, Ho, Wo, Kd, generator=g))
+    wd = _pl(torch.randn(Kd, C, generator=g) * 0.05)
+    dense = K.Planes.empty(N, H, W, C, device=DEV)
+    K.conv_bwd_data_pl(gd, wd, None, None, dense, N, H, W, C, Kd, 1, 1, 2, 0)
+    comp = K.conv1x1_s2_bwd_data_compact_pl(gd, wd, N, H, W, C, Kd)
+    assert tuple(comp.shape) == (N, Ho, Wo, C)
+    df = dense.float()
+    assert torch.equal(df[:, ::2, ::2], comp.float())
+    mask_odd = torch.ones(H, W, dtype=torch.bool); mask_odd[::2, ::2] = False
+    assert float(df[:, mask_odd.to(DEV)].abs().max()) == 0.0
+    # (2) conv1's data gradient with either residual
+    dy = _pl(torch.randn(N, H, W, Ko, generator=g))
+    w1 = _pl(torch.randn(Ko, R * R * C, generator=g) * 0.05)
+    maskin = torch.randint(0, 256, (N * H * W, C // 8), dtype=torch.uint8, generator=g).to(DEV)
+    outs = []
+    for res, s2 in ((dense, False), (comp, True)):
+        dx = K.Planes.empty(N, H, W, C, device=DEV)
+        sums = torch.empty(C, device=DEV)
+        K.conv_bwd_data_pl(dy, w1, res, maskin, dx, N, H, W, C, Ko, R, R, 1, R // 2, sums, residual_s2=s2)
+        outs.append((dx.t.clone(), sums.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    # and the residual really arrived: without it the result differs at the even pixels
+    dx0 = K.Planes.empty(N, H, W, C, device=DEV)
+    K.conv_bwd_data_pl(dy, w1, None, maskin, dx0, N, H, W, C, Ko, R, R, 1, R // 2)
+    diff = (dx0.float() - K.Planes(outs[1][0]).float()).abs()
+    assert float(diff[:, ::2, ::2].max()) > 0.0 and float(diff[:, mask_odd.to(DEV)].max()) == 0.0
+    with pytest.raises(ValueError):
+        K.conv_bwd_data_pl(dy, w1, dense, maskin, dx0, N, H, W, C, Ko, R, R, 1, R // 2, residual_s2=True)     # wrong residual shape
+
+
 def test_planes_stem_maxpool_and_mean():
     """stem (fp32 image -> planes), max-pool on planes (+ backward masked by the sign of the pooled value), mean backward."""
     N, H, C, Ko = 2, 32, 4, 64
