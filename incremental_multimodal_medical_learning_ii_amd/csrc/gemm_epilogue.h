@@ -105,11 +105,20 @@ __device__ __forceinline__ uint4 f4_bits(float a, float b, float c, float d) {
   return make_uint4(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
 }
 
-// (Round 3, tried and NOT kept: the OR over the 8 lanes of a row that assembles the ReLU decision bytes as three DPP steps —
-// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror — instead of three ds_bpermute round trips.  It took the forward
-// epilogue of conv_halo.h from 6 960 to 5 570 cycles (scripts/tune_halo.hip) and passed the kernel tests and epilogue_check, but
-// the fp32-mode data gradient of tests/test_models_gpu.py::test_image_model_forward_backward then aborted the queue without a
-// message, in a feature set that does not even store decision bits; not understood, so not shipped.)
+// OR over each aligned group of 8 lanes, result in all 8: three DPP steps on the vector ALU (lane ^ 1, lane ^ 2 inside a quad, then
+// 7 - lane inside the half row, which joins the two quads) instead of three ds_bpermute round trips through the LDS crossbar: the
+// forward epilogue of conv_halo.h went from 6 960 to 5 570 cycles (scripts/tune_halo.hip).  (First tried while the register-staged
+// kernels still spilled at 3 waves per SIMD; that build aborted an fp32-mode test — see CXRK_OCC in gemm_core.h.)
+#ifndef CXRK_OR8_DPP
+#define CXRK_OR8_DPP 1   // 0: the ds_bpermute form (A/B measurements)
+#endif
+__device__ __forceinline__ unsigned or8_lanes(unsigned x) {
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true);   // row_half_mirror
+  return x;
+}
+
 // Experiment switch (round 3, measured and NOT kept): 1 = pipeline the side inputs of the LDS-DMA kernels' epilogues (see epi_rows).
 // With it the data-gradient launches of the step took 20.34 instead of 20.45 ms and the step 154.0 instead of 155.3 ms — inside
 // the box-to-box spread — while the 256x256 instantiations went from 249 registers to 256 + 60 spilled (scratch): the epilogue is
@@ -293,8 +302,11 @@ __device__ __forceinline__ void epi_rows(f32x16 (*acc)[2][2], const EpiParams& e
       }
       if (maskout) {   // the 8 lanes of a row hold its 8 mask bytes: OR them together, lane c8 == 0 stores the 8 bytes
         unsigned w0 = c8 < 4 ? obits << (8 * c8) : 0u, w1 = c8 >= 4 ? obits << (8 * (c8 - 4)) : 0u;
+        if (CXRK_OR8_DPP) { w0 = or8_lanes(w0); w1 = or8_lanes(w1); }
+        else {
 #pragma unroll
-        for (int o = 1; o < 8; o <<= 1) { w0 |= (unsigned)__shfl_xor((int)w0, o, 64); w1 |= (unsigned)__shfl_xor((int)w1, o, 64); }
+          for (int o = 1; o < 8; o <<= 1) { w0 |= (unsigned)__shfl_xor((int)w0, o, 64); w1 |= (unsigned)__shfl_xor((int)w1, o, 64); }
+        }
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         const u32x2 w = {w0, w1};
         const unsigned mo = (rowo * (unsigned)ep.ldmaskout) | ((c8 == 0 && sd.dead[u] == 0u && col0 < N) ? 0u : VOFF_OOB);
