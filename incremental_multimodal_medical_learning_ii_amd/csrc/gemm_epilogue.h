@@ -394,13 +394,13 @@ __device__ __forceinline__ void epi_rows(f32x16 (*acc)[2][2], const EpiParams& e
 }
 #undef EH
 
-// The register-staged kernels (gemm_f32_kernel, gemm_x3_kernel).  Their code is kept exactly as it was before the compact stride-2
-// residual existed (S2RES = false, and the kinds that carry EF_RES_S2 fall through to the generic set, which a launch with
-// rs2_on never reaches here: launch_gemm refuses it): twice in round 3 an addition to this file that only touched feature sets
-// the exact-fp32 mode never runs (a DPP lane-OR in the ReLU-bits path; this residual) made fp32-mode tests fail — an aborted queue
-// in one build, one wrong beta gradient in another, deterministic per build and dependent on the order of the tests, correct again
-// with the addition removed.  Not understood (the kernels hold all 21 feature sets inline and are tens of thousands of
-// instructions long; a code-size dependent miscompilation is the suspicion), so the fp32 kernels are not touched.
+// The register-staged kernels (gemm_f32_kernel, gemm_x3_kernel) do not carry the compact stride-2 residual (S2RES = false; the
+// kinds with EF_RES_S2 fall through, and launch_gemm refuses a launch with rs2_on).  History: the first build with that feature
+// compiled into them made fp32-mode model tests fail although the exact-fp32 mode never executes it — one wrong BatchNorm beta
+// gradient, deterministic per build, dependent on the order of the tests — as had a build with the DPP lane-OR above (a silently
+// aborted queue).  Both times the 128x128 instantiations, then compiled for 3 waves per SIMD, spilled ~300 registers; the failing
+// build (-DCXRK_EXP_S2_EVERYWHERE=1) passes every test when compiled for 2 waves per SIMD, which is how these kernels are built
+// now (CXRK_OCC in gemm_core.h).  The feature stays out of them anyway: they never see such a launch.
 #ifndef CXRK_EXP_S2_EVERYWHERE
 #define CXRK_EXP_S2_EVERYWHERE 0   // experiment: 1 = compile the compact-residual code into the register-staged kernels too (the failing build)
 #endif
